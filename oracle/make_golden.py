@@ -1,0 +1,286 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (this container only).
+
+    python oracle/make_golden.py            # writes every fixture
+
+The reference is imported unmodified from /root/reference with the three
+in-process shims of SURVEY.md section 8c (collections.Iterable, a stub
+tensorboardX module, np.int).  Nothing of the reference is copied: fixtures
+hold inputs and the reference's outputs only.  `/root/reference` does not exist
+on the GPU box, so this script never runs there; the fixtures travel instead.
+"""
+import collections
+import collections.abc
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    collections.Iterable = collections.abc.Iterable                    # utility/utils.py:6
+    tb = types.ModuleType("tensorboardX")
+    tb.SummaryWriter = object
+    sys.modules["tensorboardX"] = tb                                   # utility/word.py:1
+    if not hasattr(np, "int"):
+        np.int = int                                                   # data/utils.py:73-74,91-92
+    sys.path.insert(0, REF)
+    sys.argv = ["main.py", "--model", "lightgcn"]
+    from utility.word import CFG                                       # parses argv at import
+    from utility import config as refcfg
+    import model as M
+    import model.help as H
+    import data.utils as data_utils
+    import train_data.utils as td_utils
+    import train_data.abstract as td_abs
+    import training.utils as tr_utils
+    import training.basic_test as basic_test
+    import training.basic_train as basic_train
+    return dict(CFG=CFG, cfg=refcfg, M=M, H=H, data_utils=data_utils, td_utils=td_utils, td_abs=td_abs,
+                tr_utils=tr_utils, basic_test=basic_test, basic_train=basic_train)
+
+
+def main():
+    import scipy.sparse as sp
+    import torch
+    sys.path.insert(0, ROOT)
+    import tagrec_amd
+    synth = tagrec_amd.synth
+    R = import_reference()
+    CFG, M, H = R["CFG"], R["M"], R["H"]
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+
+    def scipy_data(ds):
+        """Object shaped like TGCN_load for the model constructors."""
+        o = types.SimpleNamespace()
+        o.num = dict(ds.num)
+        mk = lambda c: sp.coo_matrix((c.data, (c.row, c.col)), shape=c.shape, dtype=np.float32)
+        o.ui_adj = mk(ds.ui_adj)
+        if ds.ut_adj is not None:
+            o.ut_adj, o.it_adj = mk(ds.ut_adj), mk(ds.it_adj)
+        return o
+
+    def blocks(ds):
+        d = {"n_user": ds.num["user"], "n_item": ds.num["item"], "n_tag": ds.num.get("tag", 0),
+             "ui_row": ds.ui_adj.row, "ui_col": ds.ui_adj.col}
+        if ds.ut_adj is not None:
+            d.update(ut_row=ds.ut_adj.row, ut_col=ds.ut_adj.col, it_row=ds.it_adj.row, it_col=ds.it_adj.col)
+        return d
+
+    def set_cfg(model, **kw):
+        CFG.update(R["cfg"].dict_map[model])
+        CFG.update(model=model, device=torch.device("cpu"), split_adj_k=1, node_drop=0.0,
+                   message_drop_list=[0.0] * 4, reg=0.0)
+        CFG.update(kw)
+
+    def coalesced(adj):
+        a = adj.coalesce()
+        return a.indices().numpy(), a.values().numpy()
+
+    toy = synth.make_cf_dataset(40, 30, 300, seed=1, n_tag=12, n_assign=200)
+    med = synth.make_cf_dataset(200, 300, 5000, seed=2)
+
+    # ------------------------------------------------------------------ adjacency (A1-A3)
+    fx = blocks(toy)
+    for use_tag in (False, True):
+        for norm in ("bi_norm", "ngcf", "si_norm", "si_norm_self", "plain"):
+            adj = H.creat_adj(scipy_data(toy), use_tag, norm, 1, torch.device("cpu"))
+            idx, val = coalesced(adj)
+            fx[f"{norm}_{int(use_tag)}_idx"], fx[f"{norm}_{int(use_tag)}_val"] = idx, val
+    folds = H.creat_adj(scipy_data(toy), True, "bi_norm", 3, torch.device("cpu"))
+    for k, f in enumerate(folds):
+        fx[f"fold3_{k}_idx"], fx[f"fold3_{k}_val"] = coalesced(f)
+        fx[f"fold3_{k}_shape"] = np.array(f.shape)
+    np.savez_compressed(os.path.join(OUT, "adj_toy.npz"), **fx)
+
+    # ------------------------------------------------------------------ helpers for model cases
+    def batches_for(ds, n_batch, B, seed):
+        tri = synth.sample_bpr_epoch(ds, seed)
+        return [tri[k * B:(k + 1) * B] for k in range(n_batch)]
+
+    def run_steps(model, loss_fn, batches, lr, n_steps):
+        """zero_grad / backward / Adam.step exactly as basic_train.epoch_training does,
+        via the reference's own epoch_training on a tiny producer object."""
+        prod = types.SimpleNamespace(reset=lambda: None,
+                                     mini_batch=lambda: iter([torch.from_numpy(b) for b in batches[:n_steps]]))
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        return R["basic_train"].epoch_training(prod, loss_fn, opt)
+
+    def model_case(name, ds, model_name, use_tag, layers, D, reg, B, seed):
+        set_cfg(model_name, use_tag=use_tag, dim_layer_list=list(layers), dim_latent=D, reg=reg)
+        torch.manual_seed(2020)                                          # init_seed (utility/utils.py:10-15)
+        cls = {"lightgcn": M.LightGCN, "ngcf": M.NGCF}[model_name]
+        model = cls(scipy_data(ds))
+        model.train()
+        fx = blocks(ds)
+        fx.update(layers=np.array(layers), D=D, reg=reg, loss_kind=CFG["mul_loss_func"], norm_type=CFG["norm_type"],
+                  use_tag=int(use_tag), lr=0.01)
+        for k, v in model.state_dict().items():
+            fx["init." + k] = v.numpy().copy()
+        bs = batches_for(ds, 3, B, seed)
+        fx["batches"] = np.stack(bs)
+        # forward + per-layer operator trace (reference operators only)
+        with torch.no_grad():
+            outs = model.forward()
+            for t, o in enumerate(outs):
+                fx[f"out.{t}"] = o.numpy().copy()
+            x = torch.cat(list(model.embed), dim=0)
+            if model_name == "lightgcn":
+                for k in range(len(layers)):
+                    x = H.split_mm(model.norm_adj, x)
+                    fx[f"raw.{k}"] = x.numpy().copy()
+        # loss parts + grads at the init point
+        lx = model.loss(torch.from_numpy(bs[0]))
+        fx["loss_parts"] = np.array([float(v) for v in lx], dtype=np.float64)
+        model.zero_grad()
+        sum(lx).backward()
+        for k, p in model.named_parameters():
+            fx["grad." + k] = p.grad.numpy().copy()
+        # 1 and 3 Adam steps from the same init, the reference's own epoch_training
+        init = {k: v.clone() for k, v in model.state_dict().items()}
+        for n in (1, 3):
+            model.load_state_dict(init)
+            losses = run_steps(model, model.loss, bs, 0.01, n)
+            fx[f"step{n}.losses"] = np.array(losses, dtype=np.float64)
+            for k, v in model.state_dict().items():
+                fx[f"step{n}." + k] = v.numpy().copy()
+        model.eval()
+        with torch.no_grad():
+            users = torch.arange(0, min(ds.num["user"], 16))
+            fx["predict.users"] = users.numpy()
+            fx["predict.rating"] = model.predict_rating(users).numpy().copy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+        print("wrote", name, {k: v for k, v in fx.items() if np.ndim(v) == 0})
+
+    model_case("lightgcn_toy", toy, "lightgcn", True, (64, 64), 64, 1e-3, 64, 11)
+    model_case("lightgcn_med", med, "lightgcn", False, (64, 64, 64), 64, 0.0, 512, 12)
+    model_case("lightgcn_toy_d32", toy, "lightgcn", False, (32,), 32, 1e-2, 48, 13)
+    model_case("ngcf_toy", toy, "ngcf", True, (64, 32, 16), 64, 1e-3, 64, 14)
+    model_case("ngcf_med", med, "ngcf", False, (64, 64, 64), 64, 0.0, 512, 15)
+
+    # ------------------------------------------------------------------ TGCN toy (T1-T6)
+    set_cfg("tgcn", use_tag=True, dim_layer_list=[16, 16], dim_latent=16, reg=1e-3, neighbor_k=5)
+    sd = scipy_data(toy)
+    sd.num["weight"] = toy.num["weight"]
+    np.random.seed(7)
+    mats = [sd.ui_adj, sd.ut_adj, sd.ui_adj.transpose(), sd.it_adj, sd.ut_adj.transpose(), sd.it_adj.transpose()]
+    tables = [R["data_utils"].all_neighbor_sample((m, int(max(m.tocsr().getnnz(1))))) for m in mats]
+    sd.get_all_neighbor = lambda: tables
+    torch.manual_seed(2020)
+    tg = M.TGCN(sd)
+    tg.train()
+    fx = blocks(toy)
+    fx.update(layers=np.array([16, 16]), D=16, reg=1e-3, neighbor_k=5, margin=CFG["margin"],
+              transtag_reg=CFG["transtag_reg"], n_weight=toy.num["weight"], lr=0.01)
+    for r, (ids, wts) in enumerate(tables):
+        fx[f"nbr{r}.ids"], fx[f"nbr{r}.wts"] = ids[:, :5].copy(), wts[:, :5].copy()
+    for k, v in tg.state_dict().items():
+        fx["init." + k] = v.numpy().copy()
+    bs = batches_for(toy, 3, 64, 21)
+    fx["batches"] = np.stack(bs)
+    rng = np.random.RandomState(5)
+    uit = toy.uit_data
+    tt = np.stack([uit[:64, 0], uit[:64, 2], uit[:64, 1], rng.randint(0, toy.num["item"], 64)], axis=1).astype(np.int64)
+    fx["tt_batch"] = tt
+    with torch.no_grad():
+        for t, o in enumerate(tg.forward()):
+            fx[f"out.{t}"] = o.numpy().copy()
+    lx = tg.loss(torch.from_numpy(bs[0]))
+    fx["loss_parts"] = np.array([float(v) for v in lx])
+    tg.zero_grad(); sum(lx).backward()
+    for k, p in tg.named_parameters():
+        fx["grad." + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    lt = tg.transtag_loss(torch.from_numpy(tt))
+    fx["tt_loss_parts"] = np.array([float(v) for v in lt])
+    tg.zero_grad(); sum(lt).backward()
+    for k in ("embed.user", "embed.item", "embed.tag"):
+        fx["tt_grad." + k] = dict(tg.named_parameters())[k].grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "tgcn_toy.npz"), **fx)
+    print("wrote tgcn_toy")
+
+    # ------------------------------------------------------------------ producer (A16, A17)
+    fx = {}
+    prod = types.SimpleNamespace()
+    cases = [(1000, 512), (1024, 512), (1536, 512), (80000, 512), (100, 512), (1025, 512), (2047, 1024)]
+    for n, B in cases:
+        prod.all_train_data = np.arange(n)
+        prod.batch_size = B
+        got = [(int(b[0]), int(b[-1]) + 1) for b in R["td_abs"].Abstract_training_data.mini_batch(prod)]
+        fx[f"mb_{n}_{B}"] = np.array(got)
+    np.random.seed(2020)
+    tr = toy.edge_index["train"]
+    fx["neg_seed"] = 2020
+    fx["neg_pos"] = tr
+    fx["neg_out"] = R["td_utils"].sample_neg_item(tr, toy.user_items["train"], toy.num["item"])
+    fx["split5"] = np.array([len(c) for c in R["td_utils"].split_data(np.arange(103), 5)])
+    np.savez_compressed(os.path.join(OUT, "producer.npz"), **fx)
+    fx_users = {str(u): np.array(v) for u, v in toy.user_items["train"].items()}
+    np.savez_compressed(os.path.join(OUT, "producer_user_items.npz"), **fx_users)
+
+    # ------------------------------------------------------------------ metrics (P1 + training/utils.py)
+    rng = np.random.RandomState(3)
+    nu, ni = 24, 60
+    rating = rng.rand(nu, ni).astype(np.float32)
+    train_items = {u: sorted(rng.choice(ni, rng.randint(1, 8), replace=False).tolist()) for u in range(nu)}
+    test_items = {u: sorted(rng.choice(ni, rng.randint(1, 6), replace=False).tolist()) for u in range(nu)}
+    CFG["topks"] = [10, 20]
+    masked = torch.from_numpy(rating.copy())
+    for u in range(nu):
+        masked[u, train_items[u]] = -(1 << 10)                          # basic_test.py:47
+    _, top = torch.topk(masked, k=20)
+    res = R["basic_test"].test_users([test_items[u] for u in range(nu)], top.numpy())
+    fx = {"rating": rating, "top": top.numpy(), "topks": np.array([10, 20])}
+    for u in range(nu):
+        fx[f"train.{u}"], fx[f"test.{u}"] = np.array(train_items[u]), np.array(test_items[u])
+    for k, v in res.items():
+        fx["res." + k] = np.array(v, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **fx)
+
+    # ------------------------------------------------------------------ end-to-end Recall@20 at C1 scale
+    c1 = synth.make_cf_dataset()                                        # 943 x 1682, 100k edges, seed 0
+    set_cfg("lightgcn", use_tag=False, dim_layer_list=[64, 64], dim_latent=64, reg=0.0)
+    torch.manual_seed(2020)
+    model = M.LightGCN(scipy_data(c1))
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    init_sum = float(sum(p.double().sum() for p in model.parameters()))
+    EPOCHS, B = 6, 512
+    loss_curve = []
+    for ep in range(EPOCHS):
+        model.train()
+        tri = torch.from_numpy(synth.sample_bpr_epoch(c1, 2020 + ep))
+        prod = types.SimpleNamespace(all_train_data=tri, batch_size=B, reset=lambda: None)
+        prod.mini_batch = lambda: R["td_abs"].Abstract_training_data.mini_batch(prod)
+        losses = R["basic_train"].epoch_training(prod, model.loss, opt)
+        loss_curve.append(float(np.mean(losses)))
+        print("e2e epoch", ep, loss_curve[-1], flush=True)
+    model.eval()
+    users = sorted(c1.user_items["test"].keys())
+    tot = collections.defaultdict(lambda: np.zeros(2))
+    with torch.no_grad():
+        for ub in R["tr_utils"].minibatch(users, 512):
+            if not len(ub):
+                continue
+            rating = model.predict_rating(torch.tensor(ub))
+            for r, u in enumerate(ub):
+                rating[r, c1.user_items["train"].get(u, [])] = -(1 << 10)
+            _, top = torch.topk(rating, k=20)
+            res = R["basic_test"].test_users([c1.user_items["test"][u] for u in ub], top.numpy())
+            for k, v in res.items():
+                tot[k] += np.array(v)
+    fx = {"epochs": EPOCHS, "batch": B, "lr": 0.01, "init_sum": init_sum, "loss_curve": np.array(loss_curve),
+          "n_test_users": len(users), "n_train_edges": len(c1.edge_index["train"]),
+          "edge_checksum": int(c1.edge_index["train"].astype(np.int64).sum())}
+    for k, v in tot.items():
+        fx["res." + k] = v / len(users)
+    np.savez_compressed(os.path.join(OUT, "e2e_c1_lightgcn.npz"), **fx)
+    print("e2e recall@[10,20]", fx["res.recall"], "ndcg", fx["res.ndcg"])
+
+
+if __name__ == "__main__":
+    main()
