@@ -1,0 +1,119 @@
+/* tagrec.h -- C ABI of libtagrec_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (chenzheng5555/tag-aware-recommendation) has no FFI: its hot path
+ * is in-process Python calling PyTorch operators.  Each entry point below replaces
+ * the PyTorch operator sequence at the cited reference lines; the Python host in
+ * `tag-aware-recommendation_amd/` mirrors the reference's operator / model / step
+ * surface and binds these symbols with ctypes (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (PyTorch storage);
+ *     the library never frees caller memory.  Row-major, contiguous, fp32.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call is asynchronous on that stream unless stated otherwise.
+ *   - return value: 0 = TAGREC_OK, negative = TAGREC_E_*; the message for the last
+ *     failing call of the calling thread is tagrec_last_error().  No C++ exception
+ *     crosses the ABI.
+ *   - a handle may be used from one thread at a time; distinct handles are independent.
+ *   - D (row width) must be a multiple of 4 and rows 16-byte aligned for the vector
+ *     kernels; other widths take a scalar kernel (correct, slower).
+ */
+#ifndef TAGREC_H
+#define TAGREC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAGREC_OK 0
+#define TAGREC_E_INVALID (-1)     /* bad argument (null pointer, negative size, bad enum) */
+#define TAGREC_E_HIP (-2)         /* a HIP runtime call failed; message holds hipGetErrorString */
+#define TAGREC_E_UNSUPPORTED (-3) /* shape outside what the kernels cover */
+#define TAGREC_E_NOMEM (-4)
+
+#define TAGREC_LOSS_SOFTPLUS 0    /* mean softplus(neg - pos)        (loss.py:11) */
+#define TAGREC_LOSS_LOGSIGMOID 1  /* -mean logsigmoid(pos - neg)     (loss.py:9)  */
+
+#define TAGREC_ABI_VERSION 1
+
+typedef struct tagrec_graph tagrec_graph;
+
+int tagrec_abi_version(void);
+const char* tagrec_last_error(void);
+/* number of CUs / wavefront size / gcnArchName of the current device (synchronous) */
+int tagrec_device_info(int* n_cu, int* wave_size, char* arch, int arch_len);
+
+/* ---- sparse normalised adjacency ------------------------------------------------
+ * A CSR matrix (int64 rowptr[n_rows+1], int32 colidx[nnz], fp32 vals[nnz]) as built by
+ * model/help/adj.py:38-46 `creat_adj` (+ :144-150 `sp2tensor`).  The arrays are BORROWED:
+ * they must outlive the handle.  Creation scans the row lengths once (synchronises the
+ * stream) and splits rows longer than 1024 entries into 512-entry chunks that are
+ * reduced in a fixed order, so results do not depend on scheduling. */
+int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                        const int64_t* rowptr, const int32_t* colidx, const float* vals, void* stream);
+int tagrec_graph_destroy(tagrec_graph* g);
+int tagrec_graph_info(const tagrec_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
+                      int64_t* n_long_rows, int64_t* n_chunks);
+
+/* Y[n_rows,D] = A @ X[n_cols,D]            -- `split_mm` / torch.sparse.mm, adj.py:158-167.
+ * The autograd backward dX = A^T dY is the same call on the transposed graph
+ * (bi_norm adjacency is symmetric: the same handle). */
+int tagrec_spmm_f32(const tagrec_graph* g, const float* X, float* Y, int D, void* stream);
+
+/* One LightGCN layer, fused (lightgcn.py:54-58 + the mean of :60):
+ *   Y_raw = A @ X;  inv_norm[r] = 1 / max(||Y_raw[r]||_2, 1e-12);
+ *   acc[r] += acc_scale * Y_raw[r] / max(||Y_raw[r]||_2, 1e-12)
+ * Y_raw feeds the next layer; acc is the running layer mean. */
+int tagrec_spmm_norm_acc_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
+                             float* acc, float acc_scale, int D, void* stream);
+
+/* Backward of one layer, fused:  G_out = A @ G_in + normalize_bwd(X_raw, inv_norm, d_scale * dZ)
+ * where normalize_bwd is the gradient of F.normalize(p=2, eps=1e-12) (lightgcn.py:57) at X_raw. */
+int tagrec_spmm_normbwd_f32(const tagrec_graph* g, const float* G_in, const float* X_raw,
+                            const float* inv_norm, const float* dZ, float d_scale, float* G_out,
+                            int D, void* stream);
+
+/* G_out = A @ G_in + b_scale * B      (last backward hop into the ego table; NGCF dX = dX_direct + A^T dN) */
+int tagrec_spmm_axpy_f32(const tagrec_graph* g, const float* G_in, const float* B, float b_scale,
+                         float* G_out, int D, void* stream);
+
+/* ---- F.normalize(p=2, dim=1, eps=1e-12) as standalone kernels (ngcf.py:86, tgcn.py:220-222) ----
+ * fwd: Z (row stride ldz floats, so it can write one slot of a concat buffer) and inv_norm.
+ * bwd: dX = normalize_bwd(X_raw, inv_norm, d_scale * dZ); dZ has row stride lddz; if `accumulate`
+ *      the result is added to dX. */
+int tagrec_rownorm_fwd_f32(const float* X, float* Z, int64_t ldz, float* inv_norm, int64_t n_rows, int D, void* stream);
+int tagrec_rownorm_bwd_f32(const float* X_raw, const float* inv_norm, const float* dZ, int64_t lddz,
+                           float d_scale, float* dX, int accumulate, int64_t n_rows, int D, void* stream);
+
+/* ---- BPR triplet loss (lightgcn.py:68-82, ngcf.py:95-105, loss.py:4-12, 27-32) -------------------
+ * trip: int64 [B,3] = (user, pos_item, neg_item), item ids local to the item table.
+ * U/I: propagated user/item tables (row stride ld floats, width D); Ureg/Ireg (stride ldreg, width Dreg):
+ * the rows the L2 term reads (ego tables for LightGCN, the propagated ones for NGCF/TGCN).
+ * fwd writes loss_out[0] = mul_loss, loss_out[1] = l2reg_loss (unweighted), and coef[b] =
+ * d mul_loss_b / d(neg_b - pos_b) (a sigmoid) for the backward.  `partials` is scratch of
+ * 2*ceil(B/256) floats; the two-stage reduction is deterministic. */
+int tagrec_bpr_fwd_f32(const float* U, const float* I, int64_t ld, int D,
+                       const float* Ureg, const float* Ireg, int64_t ldreg, int Dreg,
+                       const int64_t* trip, int64_t B, int loss_kind,
+                       float* coef, float* partials, float* loss_out, void* stream);
+/* bwd scatter-adds (float atomics) into dU/dI (stride ld) and dUreg/dIreg (stride ldreg):
+ *   dU[u] += g0*coef/B * (I[n]-I[p]);  dI[p] -= g0*coef/B * U[u];  dI[n] += g0*coef/B * U[u]
+ *   dXreg[row] += g1 * reg / B * Xreg[row]     for the three rows of every triplet
+ * g = device pointer to two floats (upstream gradients of the two loss parts) or NULL for (1,1).
+ * Callers zero the gradient buffers.  dU = dI = NULL runs the L2 part only (so it can be added
+ * after the propagation backward has overwritten the ego gradient). */
+int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, int D,
+                       const float* Ureg, const float* Ireg, int64_t ldreg, int Dreg,
+                       const int64_t* trip, int64_t B, const float* coef, const float* g, float reg,
+                       float* dU, float* dI, float* dUreg, float* dIreg, void* stream);
+
+/* ---- Adam (torch.optim.Adam defaults as used at com.py:14,25,69), one fused pass -----------------
+ *   m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
+int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
+                    float lr, float b1, float b2, float eps, int64_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAGREC_H */

@@ -4,7 +4,22 @@ Python host code (this package) mirrors the reference's operator / model / step
 surface and calls a C-ABI HIP library
 (`csrc/` -> `libtagrec_hip.so`, declared in `include/tagrec.h`) through ctypes.
 There is no CPU fallback: every op raises if the library or a GPU is missing.
+
+Reference name                      here
+  model.help.split_mm / mul_loss ...  tagrec_amd.help
+  model.LightGCN                      tagrec_amd.LightGCN
+  train_data.BPR_training_data        tagrec_amd.BPR_training_data
+  training.Basic_train / Basic_test   tagrec_amd.Basic_train / Basic_test
+  training.basic_train.epoch_training tagrec_amd.epoch_training
+  utility.word.CFG                    tagrec_amd.CFG (get_config(model, **kw))
 """
 from . import synth  # noqa: F401
-
-__all__ = ["synth"]
+from . import _lib, config, graph, help  # noqa: F401
+from ._lib import TagrecError  # noqa: F401
+from .config import CFG, get_config, init_seed  # noqa: F401
+from .evaluate import Basic_test  # noqa: F401
+from .graph import Graph, creat_adj  # noqa: F401
+from .lightgcn import LightGCN  # noqa: F401
+from .train import Adam, Basic_train, Early_stop, epoch_training  # noqa: F401
+from .train_data import (Abstract_training_data, BPR_training_data, Fixed_training_data,  # noqa: F401
+                         TransTag_training_data)

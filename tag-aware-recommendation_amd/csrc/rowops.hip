@@ -1,0 +1,299 @@
+// K2 / K4 / K5: row normalisation, BPR triplet loss (forward + scatter backward), fused Adam.
+//
+// Replaces, in the reference (/root/reference):
+//   F.normalize(p=2, dim=1)                      model/ngcf.py:86, model/tgcn.py:220-222
+//   advanced-index gathers + mul_loss + l2reg    model/lightgcn.py:68-82, model/help/loss.py:4-12, 27-32
+//   index_put_(accumulate=True) in autograd      (backward of the gathers above)
+//   torch.optim.Adam.step                        com.py:14,25,69
+// All HBM-bound; one wavefront (or a power-of-two slice of one) owns one row / triplet, reductions
+// are cross-lane shuffles, the loss sum is a fixed-order two-stage reduction.
+#include "common.h"
+
+namespace tagrec {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < kWave; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F.normalize: one wave per row, lanes stride the columns.
+__global__ __launch_bounds__(kThreads) void rownorm_fwd_kernel(const float* __restrict__ X, float* __restrict__ Z,
+                                                               int64_t ldz, float* __restrict__ inv_norm,
+                                                               int64_t n_rows, int D) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const float* x = X + r * D;
+  float ss = 0.f;
+  for (int k = lane; k < D; k += kWave) ss = fmaf(x[k], x[k], ss);
+  ss = wave_sum(ss);
+  const float den = fmaxf(sqrtf(ss), 1e-12f);
+  float* z = Z + r * ldz;
+  for (int k = lane; k < D; k += kWave) z[k] = x[k] / den;
+  if (lane == 0 && inv_norm) inv_norm[r] = 1.0f / den;
+}
+
+__global__ __launch_bounds__(kThreads) void rownorm_bwd_kernel(const float* __restrict__ Xraw,
+                                                               const float* __restrict__ inv_norm,
+                                                               const float* __restrict__ dZ, int64_t lddz, float s,
+                                                               float* __restrict__ dX, int accumulate,
+                                                               int64_t n_rows, int D) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const float inv = inv_norm[r];
+  const float* x = Xraw + r * D;
+  const float* dz = dZ + r * lddz;
+  float dot = 0.f;
+  for (int k = lane; k < D; k += kWave) dot = fmaf(x[k] * inv, dz[k] * s, dot);
+  dot = wave_sum(dot);
+  if (inv >= 1e12f) dot = 0.f;  // norm was clamped to eps: the denominator is a constant
+  float* o = dX + r * D;
+  for (int k = lane; k < D; k += kWave) {
+    const float g = inv * (dz[k] * s - x[k] * inv * dot);
+    o[k] = accumulate ? o[k] + g : g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BPR forward: one wave per triplet.  pos = u.p, neg = u.n; per-triplet loss + sigmoid coefficient;
+// block partial sums (loss, 0.5*||.||^2) in triplet order.
+__device__ __forceinline__ float softplus_torch(float x) {  // F.softplus(beta=1, threshold=20)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float neg_logsigmoid_torch(float y) {  // -F.logsigmoid(y)
+  return -(fminf(y, 0.f) - log1pf(expf(-fabsf(y))));
+}
+
+__global__ __launch_bounds__(kThreads) void bpr_fwd_kernel(const float* __restrict__ U, const float* __restrict__ I,
+                                                           int64_t ld, int D, const float* __restrict__ Ur,
+                                                           const float* __restrict__ Ir, int64_t ldr, int Dr,
+                                                           const int64_t* __restrict__ trip, int64_t B, int loss_kind,
+                                                           float* __restrict__ coef, float* __restrict__ partials) {
+  __shared__ float sh[2][kThreads / kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = threadIdx.x >> 6;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + w;
+  float loss = 0.f, reg = 0.f;
+  if (b < B) {
+    const int64_t u = trip[3 * b], p = trip[3 * b + 1], n = trip[3 * b + 2];
+    const float* ur = U + u * ld;
+    const float* pr = I + p * ld;
+    const float* nr = I + n * ld;
+    float pos = 0.f, neg = 0.f;
+    for (int k = lane; k < D; k += kWave) {
+      const float uv = ur[k];
+      pos = fmaf(uv, pr[k], pos);
+      neg = fmaf(uv, nr[k], neg);
+    }
+    pos = wave_sum(pos);
+    neg = wave_sum(neg);
+    const float x = neg - pos;
+    loss = (loss_kind == TAGREC_LOSS_LOGSIGMOID) ? neg_logsigmoid_torch(pos - neg) : softplus_torch(x);
+    // d loss / d x = sigmoid(x); torch's softplus passes the gradient through past the threshold
+    const float c = (loss_kind == TAGREC_LOSS_SOFTPLUS && x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
+    if (lane == 0) coef[b] = c;
+    if (Ur) {
+      const float* a = Ur + u * ldr;
+      const float* bb = Ir + p * ldr;
+      const float* cc = Ir + n * ldr;
+      float ss = 0.f;
+      for (int k = lane; k < Dr; k += kWave) ss = fmaf(a[k], a[k], fmaf(bb[k], bb[k], fmaf(cc[k], cc[k], ss)));
+      reg = 0.5f * wave_sum(ss);
+    }
+  }
+  if (lane == 0) { sh[0][w] = loss; sh[1][w] = reg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f, g = 0.f;
+    for (int i = 0; i < kThreads / kWave; ++i) { l += sh[0][i]; g += sh[1][i]; }
+    partials[2 * blockIdx.x] = l;
+    partials[2 * blockIdx.x + 1] = g;
+  }
+}
+
+// second stage: one block, fixed order
+__global__ __launch_bounds__(kThreads) void bpr_reduce_kernel(const float* __restrict__ partials, int64_t n_part,
+                                                              float inv_b, float* __restrict__ loss_out) {
+  __shared__ double sh[2][kThreads];
+  double l = 0.0, g = 0.0;
+  for (int64_t i = threadIdx.x; i < n_part; i += kThreads) { l += partials[2 * i]; g += partials[2 * i + 1]; }
+  sh[0][threadIdx.x] = l;
+  sh[1][threadIdx.x] = g;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss_out[0] = static_cast<float>(sh[0][0] * inv_b);
+    loss_out[1] = static_cast<float>(sh[1][0] * inv_b);
+  }
+}
+
+// BPR backward: purely per-column once coef is known, so lanes map to consecutive columns and every
+// atomic wave-instruction covers 256 contiguous bytes of one row (the fast shape for
+// global_atomic_add_f32 on gfx950).
+__global__ __launch_bounds__(kThreads) void bpr_bwd_kernel(const float* __restrict__ U, const float* __restrict__ I,
+                                                           int64_t ld, int D, const float* __restrict__ Ur,
+                                                           const float* __restrict__ Ir, int64_t ldr, int Dr,
+                                                           const int64_t* __restrict__ trip, int64_t B,
+                                                           const float* __restrict__ coef, const float* __restrict__ g,
+                                                           float reg, float inv_b, float* __restrict__ dU,
+                                                           float* __restrict__ dI, float* __restrict__ dUr,
+                                                           float* __restrict__ dIr) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float g0 = g ? g[0] : 1.f;
+  const float g1 = g ? g[1] : 1.f;
+  const int64_t u = trip[3 * b], p = trip[3 * b + 1], n = trip[3 * b + 2];
+  const float c = g0 * coef[b] * inv_b;
+  if (dU) {
+    for (int k = lane; k < D; k += kWave) {
+      const float uv = U[u * ld + k], pv = I[p * ld + k], nv = I[n * ld + k];
+      atomicAdd(&dU[u * ld + k], c * (nv - pv));
+      atomicAdd(&dI[p * ld + k], -c * uv);
+      atomicAdd(&dI[n * ld + k], c * uv);
+    }
+  }
+  const float cr = g1 * reg * inv_b;
+  if (Ur && cr != 0.f) {
+    for (int k = lane; k < Dr; k += kWave) {
+      atomicAdd(&dUr[u * ldr + k], cr * Ur[u * ldr + k]);
+      atomicAdd(&dIr[p * ldr + k], cr * Ir[p * ldr + k]);
+      atomicAdd(&dIr[n * ldr + k], cr * Ir[n * ldr + k]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam, 16 B per lane, grid-stride.  28 B of traffic per element.
+__global__ __launch_bounds__(kThreads) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                        float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+                                                        float w1, float b2, float w2, float step_size,
+                                                        float bc2_sqrt, float eps) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
+    const float4 gi = g[i];
+    float4 mi = m[i], vi = v[i], pi = p[i];
+#define TAGREC_ADAM1(c)                                            \
+    mi.c = mi.c + w1 * (gi.c - mi.c);             /* exp_avg.lerp_(grad, 1-b1)            */ \
+    vi.c = vi.c * b2 + (w2 * gi.c) * gi.c;        /* mul_(b2).addcmul_(grad, grad, 1-b2)  */ \
+    pi.c = pi.c - step_size * (mi.c / (sqrtf(vi.c) / bc2_sqrt + eps));
+    TAGREC_ADAM1(x) TAGREC_ADAM1(y) TAGREC_ADAM1(z) TAGREC_ADAM1(w)
+#undef TAGREC_ADAM1
+    m[i] = mi; v[i] = vi; p[i] = pi;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void adam_tail_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ m, float* __restrict__ v,
+                                                             int64_t start, int64_t n, float w1, float b2, float w2,
+                                                             float step_size, float bc2_sqrt, float eps) {
+  const int64_t i = start + static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = m[i] + w1 * (gi - m[i]);
+  const float vi = v[i] * b2 + (w2 * gi) * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+}
+
+}  // namespace tagrec
+
+using namespace tagrec;
+
+extern "C" int tagrec_rownorm_fwd_f32(const float* X, float* Z, int64_t ldz, float* inv_norm, int64_t n_rows, int D,
+                                      void* stream) {
+  TAGREC_REQUIRE(X && Z, "rownorm_fwd: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && D >= 1 && ldz >= D, "rownorm_fwd: bad shape");
+  if (n_rows == 0) return TAGREC_OK;
+  const unsigned blocks = static_cast<unsigned>((n_rows + 3) / 4);
+  rownorm_fwd_kernel<<<blocks, kThreads, 0, static_cast<hipStream_t>(stream)>>>(X, Z, ldz, inv_norm, n_rows, D);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_rownorm_bwd_f32(const float* X_raw, const float* inv_norm, const float* dZ, int64_t lddz,
+                                      float d_scale, float* dX, int accumulate, int64_t n_rows, int D, void* stream) {
+  TAGREC_REQUIRE(X_raw && inv_norm && dZ && dX, "rownorm_bwd: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && D >= 1 && lddz >= D, "rownorm_bwd: bad shape");
+  if (n_rows == 0) return TAGREC_OK;
+  const unsigned blocks = static_cast<unsigned>((n_rows + 3) / 4);
+  rownorm_bwd_kernel<<<blocks, kThreads, 0, static_cast<hipStream_t>(stream)>>>(X_raw, inv_norm, dZ, lddz, d_scale, dX,
+                                                                                accumulate, n_rows, D);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_bpr_fwd_f32(const float* U, const float* I, int64_t ld, int D, const float* Ureg,
+                                  const float* Ireg, int64_t ldreg, int Dreg, const int64_t* trip, int64_t B,
+                                  int loss_kind, float* coef, float* partials, float* loss_out, void* stream) {
+  TAGREC_REQUIRE(U && I && trip && coef && partials && loss_out, "bpr_fwd: null pointer");
+  TAGREC_REQUIRE(B >= 1 && D >= 1 && ld >= D, "bpr_fwd: bad shape");
+  TAGREC_REQUIRE((Ureg == nullptr) == (Ireg == nullptr), "bpr_fwd: Ureg/Ireg must both be given or both null");
+  TAGREC_REQUIRE(!Ureg || (Dreg >= 1 && ldreg >= Dreg), "bpr_fwd: bad reg shape");
+  TAGREC_REQUIRE(loss_kind == TAGREC_LOSS_SOFTPLUS || loss_kind == TAGREC_LOSS_LOGSIGMOID, "bpr_fwd: unknown loss_kind");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t blocks = (B + 3) / 4;
+  bpr_fwd_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, s>>>(U, I, ld, D, Ureg, Ireg, ldreg, Dreg, trip, B,
+                                                                     loss_kind, coef, partials);
+  TAGREC_LAUNCH_CHECK();
+  bpr_reduce_kernel<<<1, kThreads, 0, s>>>(partials, blocks, 1.0f / static_cast<float>(B), loss_out);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, int D, const float* Ureg,
+                                  const float* Ireg, int64_t ldreg, int Dreg, const int64_t* trip, int64_t B,
+                                  const float* coef, const float* g, float reg, float* dU, float* dI, float* dUreg,
+                                  float* dIreg, void* stream) {
+  TAGREC_REQUIRE(U && I && trip && coef, "bpr_bwd: null pointer");
+  TAGREC_REQUIRE((dU == nullptr) == (dI == nullptr), "bpr_bwd: dU/dI must both be given or both null (reg-only pass)");
+  TAGREC_REQUIRE(B >= 1 && D >= 1 && ld >= D, "bpr_bwd: bad shape");
+  TAGREC_REQUIRE(!Ureg || (Ireg && dUreg && dIreg && Dreg >= 1 && ldreg >= Dreg), "bpr_bwd: bad reg arguments");
+  const int64_t blocks = (B + 3) / 4;
+  bpr_bwd_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+      U, I, ld, D, Ureg, Ireg, ldreg, Dreg, trip, B, coef, g, reg, 1.0f / static_cast<float>(B), dU, dI, dUreg, dIreg);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                               float eps, int64_t step, void* stream) {
+  TAGREC_REQUIRE(p && g && m && v, "adam: null pointer");
+  TAGREC_REQUIRE(n >= 0 && step >= 1, "adam: bad n or step");
+  if (n == 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // same host arithmetic as torch's _single_tensor_adam (python floats = doubles)
+  const double bc1 = 1.0 - pow(static_cast<double>(b1), static_cast<double>(step));
+  const double bc2 = 1.0 - pow(static_cast<double>(b2), static_cast<double>(step));
+  const float step_size = static_cast<float>(static_cast<double>(lr) / bc1);
+  const float bc2_sqrt = static_cast<float>(sqrt(bc2));
+  const float w1 = static_cast<float>(1.0 - static_cast<double>(b1));
+  const float w2 = static_cast<float>(1.0 - static_cast<double>(b2));
+  const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
+  const int64_t n4 = vec ? n / 4 : 0;
+  if (n4 > 0) {
+    int64_t blocks = (n4 + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    adam_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, s>>>(
+        reinterpret_cast<float4*>(p), reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m),
+        reinterpret_cast<float4*>(v), n4, w1, b2, w2, step_size, bc2_sqrt, eps);
+    TAGREC_LAUNCH_CHECK();
+  }
+  const int64_t done = n4 * 4;
+  if (done < n) {
+    const int64_t blocks = (n - done + kThreads - 1) / kThreads;
+    adam_tail_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, s>>>(p, g, m, v, done, n, w1, b2, w2, step_size,
+                                                                        bc2_sqrt, eps);
+    TAGREC_LAUNCH_CHECK();
+  }
+  return TAGREC_OK;
+}

@@ -1,0 +1,488 @@
+// K1: CSR sparse-adjacency x dense-embedding product for gfx950, with the fused row
+// epilogues of the LightGCN / NGCF layers.
+//
+// Replaces torch.sparse.mm inside `split_mm` (/root/reference/model/help/adj.py:158-167) and,
+// fused behind it, F.normalize + the layer mean of `LightGCN.forward`
+// (/root/reference/model/lightgcn.py:54-60) and their autograd backward.
+//
+// Work decomposition (wave64):
+//   * one wavefront per CSR row.  A row of D fp32 = D/4 lanes x 16 B, so one
+//     global_load_dwordx4 wave-instruction gathers 64/(D/4) neighbour rows at once
+//     (D=64: 4 neighbours, 1 KiB per instruction), 4 instructions in flight per wave.
+//   * column indices / values are read 64 at a time, coalesced, and broadcast to the
+//     lane groups with ds_bpermute (__shfl).
+//   * per-lane-group partial sums are folded with cross-lane xor shuffles; the row norm
+//     is reduced the same way, so the epilogue needs no LDS and no second pass.
+//   * rows longer than kLongRow entries are cut into kChunk-entry chunks, one wave each,
+//     written to a partial-sum slab and folded in chunk order by a finishing kernel
+//     (deterministic; no float atomics).
+// HBM-bound: algorithmic bytes per stored entry = 8 + 4*D.
+#include <new>
+
+#include "common.h"
+
+namespace tagrec {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kLongRow = 1024;
+constexpr int kChunk = 512;
+constexpr int kMaxGenericBlocks = 8;  // scalar kernel keeps D <= 512 in registers
+
+enum Epi { EPI_NONE = 0, EPI_NORM_ACC = 1, EPI_NORMBWD = 2, EPI_AXPY = 3 };
+
+struct EpiArgs {
+  float* Y;               // [n_rows, D] product (or gradient) out
+  float* inv_norm;        // NORM_ACC: out; NORMBWD: in
+  float* accum;           // NORM_ACC: accum += s * normalize(y)
+  const float* Xraw;      // NORMBWD
+  const float* B;         // NORMBWD: dZ ; AXPY: B
+  float s;
+};
+
+struct GraphView {
+  int64_t n_rows;
+  const int64_t* rowptr;
+  const int32_t* col;
+  const float* val;
+};
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4_fma(float4& a, float s, const float4& x) {
+  a.x = fmaf(s, x.x, a.x); a.y = fmaf(s, x.y, a.y); a.z = fmaf(s, x.z, a.z); a.w = fmaf(s, x.w, a.w);
+}
+__device__ __forceinline__ float4 f4_shfl_xor(const float4& a, int m) {
+  return make_float4(__shfl_xor(a.x, m), __shfl_xor(a.y, m), __shfl_xor(a.z, m), __shfl_xor(a.w, m));
+}
+__device__ __forceinline__ float f4_dot(const float4& a, const float4& b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+// Sum of val[j] * X[col[j], :] over j in [start, end).  LPR = lanes per row = D/4.  On return every
+// lane holds the full sum for its float4 column (lane % LPR).
+template <int LPR>
+__device__ __forceinline__ float4 gather_rows(const GraphView& g, const float* __restrict__ X,
+                                              int64_t start, int64_t end, int lane) {
+  constexpr int NPI = kWave / LPR;  // neighbour rows per wave-instruction
+  const int q = lane / LPR;
+  const float4* __restrict__ Xv = reinterpret_cast<const float4*>(X) + (lane % LPR);
+  float4 acc = f4_zero();
+  for (int64_t base = start; base < end; base += kWave) {
+    const int n = (end - base) < kWave ? static_cast<int>(end - base) : kWave;
+    int my_col = 0;
+    float my_val = 0.f;
+    if (lane < n) {
+      my_col = g.col[base + lane];
+      my_val = g.val[base + lane];
+    }
+    const int groups = (n + NPI - 1) / NPI;
+    for (int gi = 0; gi < groups; gi += 4) {
+      float4 x[4];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = (gi + u) * NPI + q;
+        const int c = __shfl(my_col, j & (kWave - 1));
+        const float w = __shfl(my_val, j & (kWave - 1));
+        const bool ok = j < n;
+        v[u] = ok ? w : 0.f;
+        x[u] = ok ? Xv[static_cast<int64_t>(c) * LPR] : f4_zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f4_fma(acc, v[u], x[u]);
+    }
+  }
+#pragma unroll
+  for (int m = LPR; m < kWave; m <<= 1) {
+    const float4 o = f4_shfl_xor(acc, m);
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+  }
+  return acc;
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// Gradient of z = x / max(||x||, eps) given inv = 1/max(||x||, eps):
+//   ||x|| >  eps : inv * (dz - z (z . dz))
+//   ||x|| <= eps : inv * dz            (the clamp is constant there; inv == 1e12)
+template <int LPR>
+__device__ __forceinline__ float4 normalize_bwd(const float4& xr, float inv, const float4& dz) {
+  const float4 z = make_float4(xr.x * inv, xr.y * inv, xr.z * inv, xr.w * inv);
+  float dot = group_sum<LPR>(f4_dot(z, dz));
+  if (inv >= 1e12f) dot = 0.f;
+  return make_float4(inv * (dz.x - z.x * dot), inv * (dz.y - z.y * dot), inv * (dz.z - z.z * dot),
+                     inv * (dz.w - z.w * dot));
+}
+
+template <int LPR, int EPI>
+__device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, const EpiArgs& e) {
+  const bool writer = lane < LPR;
+  const int64_t off = r * LPR + (lane % LPR);  // float4 index of this lane's columns
+  if constexpr (EPI == EPI_NONE) {
+    if (writer) reinterpret_cast<float4*>(e.Y)[off] = acc;
+  } else if constexpr (EPI == EPI_NORM_ACC) {
+    const float ss = group_sum<LPR>(f4_dot(acc, acc));
+    const float den = fmaxf(sqrtf(ss), 1e-12f);
+    if (writer) {
+      reinterpret_cast<float4*>(e.Y)[off] = acc;
+      float4 a = reinterpret_cast<const float4*>(e.accum)[off];
+      a.x = fmaf(e.s, acc.x / den, a.x);
+      a.y = fmaf(e.s, acc.y / den, a.y);
+      a.z = fmaf(e.s, acc.z / den, a.z);
+      a.w = fmaf(e.s, acc.w / den, a.w);
+      reinterpret_cast<float4*>(e.accum)[off] = a;
+    }
+    if (lane == 0) e.inv_norm[r] = 1.0f / den;
+  } else if constexpr (EPI == EPI_NORMBWD) {
+    const float4 xr = reinterpret_cast<const float4*>(e.Xraw)[off];
+    float4 dz = reinterpret_cast<const float4*>(e.B)[off];
+    dz.x *= e.s; dz.y *= e.s; dz.z *= e.s; dz.w *= e.s;
+    const float4 gz = normalize_bwd<LPR>(xr, e.inv_norm[r], dz);
+    if (writer)
+      reinterpret_cast<float4*>(e.Y)[off] = make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w);
+  } else {  // EPI_AXPY
+    const float4 b = reinterpret_cast<const float4*>(e.B)[off];
+    if (writer)
+      reinterpret_cast<float4*>(e.Y)[off] = make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y),
+                                                        fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w));
+  }
+}
+
+// ---- short rows: one wave per row --------------------------------------------------------------
+template <int LPR, int EPI>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(GraphView g, const float* __restrict__ X,
+                                                                            EpiArgs e) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (r >= g.n_rows) return;
+  const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
+  if (end - start > kLongRow) return;  // chunk kernels own this row
+  const float4 acc = gather_rows<LPR>(g, X, start, end, lane);
+  row_epilogue<LPR, EPI>(acc, r, lane, e);
+}
+
+// ---- long rows: one wave per kChunk entries, partial sums to a slab ----------------------------
+template <int LPR>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_chunk_kernel(GraphView g, const float* __restrict__ X,
+                                                                             const int32_t* __restrict__ long_rows,
+                                                                             const int2* __restrict__ chunk_desc,
+                                                                             int64_t n_chunks, float* __restrict__ slab) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int2 d = chunk_desc[c];
+  const int64_t r = long_rows[d.x];
+  const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
+  const int64_t row_end = g.rowptr[r + 1];
+  const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
+  const float4 acc = gather_rows<LPR>(g, X, start, end, lane);
+  if (lane < LPR) reinterpret_cast<float4*>(slab)[c * LPR + lane] = acc;
+}
+
+template <int LPR, int EPI>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_finish_kernel(GraphView g,
+                                                                              const int32_t* __restrict__ long_rows,
+                                                                              const int32_t* __restrict__ long_base,
+                                                                              int64_t n_long, const float* __restrict__ slab,
+                                                                              EpiArgs e) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t li = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (li >= n_long) return;
+  const int64_t r = long_rows[li];
+  const int64_t deg = g.rowptr[r + 1] - g.rowptr[r];
+  const int nc = static_cast<int>((deg + kChunk - 1) / kChunk);
+  const float4* p = reinterpret_cast<const float4*>(slab) + static_cast<int64_t>(long_base[li]) * LPR + (lane % LPR);
+  float4 acc = f4_zero();
+  for (int k = 0; k < nc; ++k) {  // fixed chunk order -> reproducible sum
+    const float4 x = p[static_cast<int64_t>(k) * LPR];
+    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+  }
+  row_epilogue<LPR, EPI>(acc, r, lane, e);
+}
+
+// ---- any width D <= 512: scalar columns, one neighbour row per instruction ---------------------
+template <int EPI>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_generic_kernel(GraphView g, const float* __restrict__ X,
+                                                                                    EpiArgs e, int D) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (r >= g.n_rows) return;
+  const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
+  float acc[kMaxGenericBlocks];
+#pragma unroll
+  for (int b = 0; b < kMaxGenericBlocks; ++b) acc[b] = 0.f;
+  for (int64_t base = start; base < end; base += kWave) {
+    const int n = (end - base) < kWave ? static_cast<int>(end - base) : kWave;
+    int my_col = 0;
+    float my_val = 0.f;
+    if (lane < n) {
+      my_col = g.col[base + lane];
+      my_val = g.val[base + lane];
+    }
+    for (int j = 0; j < n; ++j) {
+      const int64_t c = __shfl(my_col, j);
+      const float w = __shfl(my_val, j);
+      const float* xr = X + c * D;
+#pragma unroll
+      for (int b = 0; b < kMaxGenericBlocks; ++b) {
+        const int k = b * kWave + lane;
+        if (k < D) acc[b] = fmaf(w, xr[k], acc[b]);
+      }
+    }
+  }
+  const int64_t row = r * D;
+  if constexpr (EPI == EPI_NONE) {
+#pragma unroll
+    for (int b = 0; b < kMaxGenericBlocks; ++b) {
+      const int k = b * kWave + lane;
+      if (k < D) e.Y[row + k] = acc[b];
+    }
+  } else if constexpr (EPI == EPI_NORM_ACC) {
+    float ss = 0.f;
+#pragma unroll
+    for (int b = 0; b < kMaxGenericBlocks; ++b) ss = fmaf(acc[b], acc[b], ss);  // lanes past D hold 0
+    ss = group_sum<kWave>(ss);
+    const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int b = 0; b < kMaxGenericBlocks; ++b) {
+      const int k = b * kWave + lane;
+      if (k < D) {
+        e.Y[row + k] = acc[b];
+        e.accum[row + k] = fmaf(e.s, acc[b] / den, e.accum[row + k]);
+      }
+    }
+    if (lane == 0) e.inv_norm[r] = 1.0f / den;
+  } else if constexpr (EPI == EPI_NORMBWD) {
+    const float inv = e.inv_norm[r];
+    float z[kMaxGenericBlocks], dz[kMaxGenericBlocks];
+    float dot = 0.f;
+#pragma unroll
+    for (int b = 0; b < kMaxGenericBlocks; ++b) {
+      const int k = b * kWave + lane;
+      z[b] = (k < D) ? e.Xraw[row + k] * inv : 0.f;
+      dz[b] = (k < D) ? e.B[row + k] * e.s : 0.f;
+      dot = fmaf(z[b], dz[b], dot);
+    }
+    dot = group_sum<kWave>(dot);
+    if (inv >= 1e12f) dot = 0.f;
+#pragma unroll
+    for (int b = 0; b < kMaxGenericBlocks; ++b) {
+      const int k = b * kWave + lane;
+      if (k < D) e.Y[row + k] = acc[b] + inv * (dz[b] - z[b] * dot);
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < kMaxGenericBlocks; ++b) {
+      const int k = b * kWave + lane;
+      if (k < D) e.Y[row + k] = fmaf(e.s, e.B[row + k], acc[b]);
+    }
+  }
+}
+
+// ---- row-length scan at graph creation ---------------------------------------------------------
+__global__ void count_long_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, unsigned long long* counters) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const int64_t deg = rowptr[r + 1] - rowptr[r];
+  if (deg > kLongRow) {
+    atomicAdd(&counters[0], 1ull);
+    atomicAdd(&counters[1], static_cast<unsigned long long>((deg + kChunk - 1) / kChunk));
+  }
+}
+
+__global__ void fill_long_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, unsigned long long* counters,
+                                 int32_t* long_rows, int32_t* long_base, int2* chunk_desc) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const int64_t deg = rowptr[r + 1] - rowptr[r];
+  if (deg > kLongRow) {
+    const int nc = static_cast<int>((deg + kChunk - 1) / kChunk);
+    const int li = static_cast<int>(atomicAdd(&counters[2], 1ull));
+    const int base = static_cast<int>(atomicAdd(&counters[3], static_cast<unsigned long long>(nc)));
+    long_rows[li] = static_cast<int32_t>(r);
+    long_base[li] = base;
+    for (int k = 0; k < nc; ++k) chunk_desc[base + k] = make_int2(li, k);
+  }
+}
+
+}  // namespace tagrec
+
+using namespace tagrec;
+
+struct tagrec_graph {
+  int64_t n_rows, n_cols, nnz;
+  const int64_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  int64_t n_long, n_chunks;
+  int32_t* long_rows;
+  int32_t* long_base;
+  int2* chunk_desc;
+  mutable float* slab;        // n_chunks x D partial sums, grown on demand
+  mutable size_t slab_floats;
+};
+
+extern "C" int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                   const int64_t* rowptr, const int32_t* colidx, const float* vals, void* stream) {
+  TAGREC_REQUIRE(out != nullptr, "graph_create: out is null");
+  TAGREC_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "graph_create: negative size");
+  TAGREC_REQUIRE(n_rows < (1ll << 31) && n_cols < (1ll << 31), "graph_create: node ids must fit int32");
+  TAGREC_REQUIRE(rowptr != nullptr, "graph_create: rowptr is null");
+  TAGREC_REQUIRE(nnz == 0 || (colidx != nullptr && vals != nullptr), "graph_create: colidx/vals null with nnz > 0");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  tagrec_graph* g = new (std::nothrow) tagrec_graph();
+  if (!g) return fail(TAGREC_E_NOMEM, "graph_create: host allocation failed");
+  *g = tagrec_graph{n_rows, n_cols, nnz, rowptr, colidx, vals, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  if (n_rows > 0) {
+    unsigned long long* counters = nullptr;
+    unsigned long long host[4] = {0, 0, 0, 0};
+    hipError_t err = hipMalloc(&counters, sizeof(host));
+    if (err != hipSuccess) { delete g; return fail(TAGREC_E_HIP, std::string("graph_create: hipMalloc: ") + hipGetErrorString(err)); }
+    auto bail = [&](const char* what, hipError_t e2) {
+      (void)hipFree(counters); (void)hipFree(g->long_rows); (void)hipFree(g->long_base); (void)hipFree(g->chunk_desc);
+      delete g;
+      return fail(TAGREC_E_HIP, std::string("graph_create: ") + what + ": " + hipGetErrorString(e2));
+    };
+    const int threads = 256;
+    const unsigned blocks = static_cast<unsigned>((n_rows + threads - 1) / threads);
+    if ((err = hipMemsetAsync(counters, 0, sizeof(host), s)) != hipSuccess) return bail("memset", err);
+    count_long_kernel<<<blocks, threads, 0, s>>>(rowptr, n_rows, counters);
+    if ((err = hipGetLastError()) != hipSuccess) return bail("count_long launch", err);
+    if ((err = hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail("memcpy", err);
+    if ((err = hipStreamSynchronize(s)) != hipSuccess) return bail("sync", err);
+    g->n_long = static_cast<int64_t>(host[0]);
+    g->n_chunks = static_cast<int64_t>(host[1]);
+    if (g->n_long > 0) {
+      if (g->n_chunks >= (1ll << 31)) { (void)hipFree(counters); delete g; return fail(TAGREC_E_UNSUPPORTED, "graph_create: too many long-row chunks"); }
+      if ((err = hipMalloc(&g->long_rows, sizeof(int32_t) * g->n_long)) != hipSuccess) return bail("hipMalloc long_rows", err);
+      if ((err = hipMalloc(&g->long_base, sizeof(int32_t) * g->n_long)) != hipSuccess) return bail("hipMalloc long_base", err);
+      if ((err = hipMalloc(&g->chunk_desc, sizeof(int2) * g->n_chunks)) != hipSuccess) return bail("hipMalloc chunk_desc", err);
+      fill_long_kernel<<<blocks, threads, 0, s>>>(rowptr, n_rows, counters, g->long_rows, g->long_base, g->chunk_desc);
+      if ((err = hipGetLastError()) != hipSuccess) return bail("fill_long launch", err);
+      if ((err = hipStreamSynchronize(s)) != hipSuccess) return bail("sync", err);
+    }
+    (void)hipFree(counters);
+  }
+  *out = g;
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_graph_destroy(tagrec_graph* g) {
+  if (!g) return TAGREC_OK;
+  (void)hipFree(g->long_rows);
+  (void)hipFree(g->long_base);
+  (void)hipFree(g->chunk_desc);
+  (void)hipFree(g->slab);
+  delete g;
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_graph_info(const tagrec_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
+                                 int64_t* n_long_rows, int64_t* n_chunks) {
+  TAGREC_REQUIRE(g != nullptr, "graph_info: null handle");
+  if (n_rows) *n_rows = g->n_rows;
+  if (n_cols) *n_cols = g->n_cols;
+  if (nnz) *nnz = g->nnz;
+  if (n_long_rows) *n_long_rows = g->n_long;
+  if (n_chunks) *n_chunks = g->n_chunks;
+  return TAGREC_OK;
+}
+
+namespace {
+
+int ensure_slab(const tagrec_graph* g, int D) {
+  const size_t need = static_cast<size_t>(g->n_chunks) * D;
+  if (need <= g->slab_floats) return TAGREC_OK;
+  if (g->slab) TAGREC_HIP(hipFree(g->slab));
+  g->slab = nullptr;
+  g->slab_floats = 0;
+  TAGREC_HIP(hipMalloc(&g->slab, need * sizeof(float)));
+  g->slab_floats = need;
+  return TAGREC_OK;
+}
+
+template <int LPR, int EPI>
+int launch_vec(const tagrec_graph* g, const float* X, const EpiArgs& e, hipStream_t s) {
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const int threads = kWavesPerBlock * kWave;
+  const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (g->n_long > 0) {
+    int rc = ensure_slab(g, LPR * 4);
+    if (rc != TAGREC_OK) return rc;
+    const unsigned cblocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+    spmm_chunk_kernel<LPR><<<cblocks, threads, 0, s>>>(gv, X, g->long_rows, g->chunk_desc, g->n_chunks, g->slab);
+    TAGREC_LAUNCH_CHECK();
+  }
+  spmm_rows_kernel<LPR, EPI><<<blocks, threads, 0, s>>>(gv, X, e);
+  TAGREC_LAUNCH_CHECK();
+  if (g->n_long > 0) {
+    const unsigned fblocks = static_cast<unsigned>((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+    spmm_finish_kernel<LPR, EPI><<<fblocks, threads, 0, s>>>(gv, g->long_rows, g->long_base, g->n_long, g->slab, e);
+    TAGREC_LAUNCH_CHECK();
+  }
+  return TAGREC_OK;
+}
+
+template <int EPI>
+int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, void* stream, const char* who) {
+  TAGREC_REQUIRE(g != nullptr, std::string(who) + ": null graph handle");
+  TAGREC_REQUIRE(X != nullptr && e.Y != nullptr, std::string(who) + ": null X or output");
+  TAGREC_REQUIRE(D >= 1, std::string(who) + ": D must be >= 1");
+  TAGREC_REQUIRE(static_cast<const void*>(X) != static_cast<const void*>(e.Y), std::string(who) + ": output aliases the gathered input");
+  if (g->n_rows == 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bool vec_ok = aligned16(X) && aligned16(e.Y);
+  if (e.accum) vec_ok = vec_ok && aligned16(e.accum);
+  if (e.Xraw) vec_ok = vec_ok && aligned16(e.Xraw);
+  if (e.B) vec_ok = vec_ok && aligned16(e.B);
+  if (vec_ok) {
+    switch (D) {
+      case 16: return launch_vec<4, EPI>(g, X, e, s);
+      case 32: return launch_vec<8, EPI>(g, X, e, s);
+      case 64: return launch_vec<16, EPI>(g, X, e, s);
+      case 128: return launch_vec<32, EPI>(g, X, e, s);
+      case 256: return launch_vec<64, EPI>(g, X, e, s);
+      default: break;
+    }
+  }
+  if (D > kMaxGenericBlocks * kWave)
+    return fail(TAGREC_E_UNSUPPORTED, std::string(who) + ": row width " + std::to_string(D) + " > 512 is not covered");
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  spmm_rows_generic_kernel<EPI><<<blocks, kWavesPerBlock * kWave, 0, s>>>(gv, X, e, D);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+}  // namespace
+
+extern "C" int tagrec_spmm_f32(const tagrec_graph* g, const float* X, float* Y, int D, void* stream) {
+  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, 0.f};
+  return launch_spmm<EPI_NONE>(g, X, e, D, stream, "spmm");
+}
+
+extern "C" int tagrec_spmm_norm_acc_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
+                                        float* acc, float acc_scale, int D, void* stream) {
+  TAGREC_REQUIRE(inv_norm != nullptr && acc != nullptr, "spmm_norm_acc: null inv_norm or acc");
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, acc_scale};
+  return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc");
+}
+
+extern "C" int tagrec_spmm_normbwd_f32(const tagrec_graph* g, const float* G_in, const float* X_raw,
+                                       const float* inv_norm, const float* dZ, float d_scale, float* G_out,
+                                       int D, void* stream) {
+  TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr, "spmm_normbwd: null X_raw, inv_norm or dZ");
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, d_scale};
+  return launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd");
+}
+
+extern "C" int tagrec_spmm_axpy_f32(const tagrec_graph* g, const float* G_in, const float* B, float b_scale,
+                                    float* G_out, int D, void* stream) {
+  TAGREC_REQUIRE(B != nullptr, "spmm_axpy: null B");
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, b_scale};
+  return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy");
+}

@@ -1,0 +1,275 @@
+"""Normalised block adjacency -> device CSR -> `Graph` handle of the HIP library.
+
+Host-side counterpart of /root/reference/model/help/adj.py:
+  `create_ui_adj` / `create_uit_adj` (:7-35), `get_norm_adj` and the two
+  Laplacians (:75-110), `split_sp_mat` / `split_sp2tensor` (:114-140) and
+  `creat_adj` (:38-46).  The reference goes scipy LIL -> torch sparse COO; here
+  the CSR is built directly (sort + segment sum) either on the host in numpy --
+  bit-identical values to the reference's scipy arithmetic -- or on the GPU with
+  torch ops for graphs that are generated on the device and never visit the host.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+NORM_TYPES = ("bi_norm", "si_norm", "si_norm_self", "ngcf")
+
+
+# ---------------------------------------------------------------------------------- host build
+def _coalesce_host(rows, cols, vals, n_r, n_c):
+    key = rows.astype(np.int64) * n_c + cols.astype(np.int64)
+    order = np.argsort(key, kind="stable")
+    key, vals = key[order], vals[order].astype(np.float64)
+    head = np.ones(len(key), dtype=bool)
+    head[1:] = key[1:] != key[:-1]
+    starts = np.flatnonzero(head)
+    ukey = key[starts]
+    uval = np.add.reduceat(vals, starts).astype(np.float32) if len(key) else np.zeros(0, np.float32)
+    deg = np.bincount(ukey // n_c, minlength=n_r)
+    rowptr = np.zeros(n_r + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    return rowptr, (ukey % n_c).astype(np.int32), uval
+
+
+def _block(coo):
+    """Accepts a scipy COO matrix or anything with .row .col .data .shape."""
+    if hasattr(coo, "tocoo"):
+        coo = coo.tocoo()
+    return (np.asarray(coo.row, np.int64), np.asarray(coo.col, np.int64),
+            np.asarray(coo.data, np.float32), tuple(int(s) for s in coo.shape))
+
+
+def block_adjacency_host(ui_adj, ut_adj=None, it_adj=None):
+    """Symmetric [user | item | tag] block adjacency as CSR (adj.py:7-35).
+    Repeated (row, col) pairs inside a block are summed, which is how the
+    reference's tag blocks get integer weights (data/utils.py:50-53)."""
+    r, c, v, (n_u, n_i) = _block(ui_adj)
+    rows, cols, vals = [r, c + n_u], [c + n_u, r], [v, v]
+    n = n_u + n_i
+    if ut_adj is not None:
+        r2, c2, v2, (_, n_t) = _block(ut_adj)
+        r3, c3, v3, _ = _block(it_adj)
+        rows += [r2, c2 + n, r3 + n_u, c3 + n]
+        cols += [c2 + n, r2, c3 + n, r3 + n_u]
+        vals += [v2, v2, v3, v3]
+        n += n_t
+    rowptr, col, val = _coalesce_host(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), n, n)
+    return rowptr, col, val, n
+
+
+def normalise_host(rowptr, col, val, n, norm_type):
+    """`get_norm_adj` (adj.py:75-87) in the reference's fp32 operation order:
+    (d[r] * a) * d[c] for bi_norm, d[r] * a for the row-stochastic forms."""
+    def add_eye(rowptr, col, val):
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+        eye = np.arange(n, dtype=np.int64)
+        return _coalesce_host(np.concatenate([rows, eye]), np.concatenate([col.astype(np.int64), eye]),
+                              np.concatenate([val, np.ones(n, np.float32)]), n, n)
+
+    if norm_type == "si_norm_self":
+        rowptr, col, val = add_eye(rowptr, col, val)
+    if norm_type not in NORM_TYPES:
+        return rowptr, col, val
+    deg = np.diff(rowptr)
+    rs = np.zeros(n, dtype=np.float32)
+    nz = np.flatnonzero(deg > 0)
+    if nz.size:
+        rs[nz] = np.add.reduceat(val.astype(np.float64), rowptr[nz]).astype(np.float32)
+    rows = np.repeat(np.arange(n, dtype=np.int64), deg)
+    with np.errstate(divide="ignore"):
+        if norm_type == "bi_norm":
+            d = np.power(rs, np.float32(-0.5)).astype(np.float32)
+            d[np.isinf(d)] = 0.0
+            val = (d[rows] * val).astype(np.float32) * d[col]
+        else:
+            d = np.power(rs, np.float32(-1)).astype(np.float32)
+            d[np.isinf(d)] = 0.0
+            val = (d[rows] * val).astype(np.float32)
+    val = val.astype(np.float32)
+    if norm_type == "ngcf":
+        rowptr, col, val = add_eye(rowptr, col, val)
+    return rowptr, col, val
+
+
+def fold_bounds(n_rows, k):
+    """`split_sp_mat` (adj.py:114-130): fold_len = n // k, the last fold takes the rest."""
+    if k < 2:
+        return [(0, n_rows)]
+    fold = n_rows // k
+    return [(i * fold, n_rows if i == k - 1 else (i + 1) * fold) for i in range(k)]
+
+
+# ---------------------------------------------------------------------------------- device build
+def coalesce_device(rows, cols, vals, n_r, n_c):
+    """Sort-based COO -> CSR on the GPU (int64 keys); duplicates summed."""
+    key = rows.to(torch.int64) * n_c + cols.to(torch.int64)
+    key, order = torch.sort(key)
+    vals = vals[order]
+    ukey, inv = torch.unique_consecutive(key, return_inverse=True)
+    if ukey.numel() != key.numel():
+        uval = torch.zeros(ukey.numel(), dtype=torch.float32, device=key.device).index_add_(0, inv, vals)
+    else:
+        uval = vals
+    urow = torch.div(ukey, n_c, rounding_mode="floor")
+    deg = torch.bincount(urow, minlength=n_r)
+    rowptr = torch.zeros(n_r + 1, dtype=torch.int64, device=key.device)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    return rowptr, (ukey - urow * n_c).to(torch.int32), uval.to(torch.float32)
+
+
+def bipartite_norm_device(u, i, n_user, n_item, norm_type="bi_norm"):
+    """User-item adjacency straight on the GPU: u, i int64 tensors of DISTINCT pairs.
+    Returns (rowptr, col, val, n).  Same formulas as `normalise_host`."""
+    n = n_user + n_item
+    rows = torch.cat([u, i + n_user])
+    cols = torch.cat([i + n_user, u])
+    vals = torch.ones(rows.numel(), dtype=torch.float32, device=u.device)
+    rowptr, col, val = coalesce_device(rows, cols, vals, n, n)
+    del rows, cols, vals
+    deg = (rowptr[1:] - rowptr[:-1])
+    rs = deg.to(torch.float32)                       # unit weights: row sum == degree
+    r_of = torch.repeat_interleave(torch.arange(n, device=u.device), deg)
+    if norm_type == "bi_norm":
+        d = torch.pow(rs, -0.5)
+        d[torch.isinf(d)] = 0.0
+        val = (d[r_of] * val) * d[col.long()]
+    elif norm_type in ("si_norm", "ngcf"):
+        d = torch.pow(rs, -1.0)
+        d[torch.isinf(d)] = 0.0
+        val = d[r_of] * val
+        if norm_type == "ngcf":
+            eye = torch.arange(n, device=u.device)
+            rowptr, col, val = coalesce_device(torch.cat([r_of, eye]), torch.cat([col.long(), eye]),
+                                               torch.cat([val, torch.ones(n, device=u.device)]), n, n)
+    elif norm_type != "plain":
+        raise ValueError(f"unknown norm_type {norm_type!r}")
+    return rowptr, col, val.contiguous(), n
+
+
+# ---------------------------------------------------------------------------------- handle
+class Graph:
+    """Device CSR + the library handle built on it.  Owns the three tensors (the
+    library only borrows them) and, lazily, the transposed graph for backward."""
+
+    def __init__(self, rowptr, col, val, shape, symmetric=False):
+        self.rowptr = _lib.require_gpu_tensor(rowptr, torch.int64, "rowptr")
+        self.col = _lib.require_gpu_tensor(col, torch.int32, "col")
+        self.val = _lib.require_gpu_tensor(val, torch.float32, "val")
+        self.shape = (int(shape[0]), int(shape[1]))
+        if rowptr.numel() != self.shape[0] + 1 or col.numel() != val.numel():
+            raise _lib.TagrecError("Graph: inconsistent CSR array sizes")
+        self.symmetric = bool(symmetric) and self.shape[0] == self.shape[1]
+        self._T = None
+        self._h = _lib.c_void_p()
+        lib = _lib.load()
+        with torch.cuda.device(self.val.device):
+            _lib.check(lib.tagrec_graph_create(_lib.ctypes.byref(self._h), self.shape[0], self.shape[1], col.numel(),
+                                               _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()),
+                       "graph_create")
+
+    @classmethod
+    def from_host(cls, rowptr, col, val, shape, device, symmetric=False):
+        dev = torch.device(device)
+        return cls(torch.from_numpy(np.ascontiguousarray(rowptr, np.int64)).to(dev),
+                   torch.from_numpy(np.ascontiguousarray(col, np.int32)).to(dev),
+                   torch.from_numpy(np.ascontiguousarray(val, np.float32)).to(dev), shape, symmetric)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.load().tagrec_graph_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def device(self):
+        return self.val.device
+
+    @property
+    def nnz(self):
+        return int(self.col.numel())
+
+    def info(self):
+        out = [_lib.c_int64() for _ in range(5)]
+        _lib.check(_lib.load().tagrec_graph_info(self._h, *[_lib.ctypes.byref(o) for o in out]), "graph_info")
+        return dict(zip(("n_rows", "n_cols", "nnz", "n_long_rows", "n_chunks"), (o.value for o in out)))
+
+    def transpose(self):
+        """A^T as its own Graph (what the autograd backward of `split_mm` multiplies by).
+        The bi_norm adjacency is symmetric, so it is its own transpose."""
+        if self.symmetric:
+            return self
+        if self._T is None:
+            deg = self.rowptr[1:] - self.rowptr[:-1]
+            rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device), deg)
+            rp, c, v = coalesce_device(self.col.long(), rows, self.val, self.shape[1], self.shape[0])
+            self._T = Graph(rp, c, v, (self.shape[1], self.shape[0]))
+            self._T._T = self
+        return self._T
+
+    # -- raw kernel entry points (no autograd) ---------------------------------------------------
+    def _chk_x(self, X, rows, name):
+        _lib.require_gpu_tensor(X, torch.float32, name)
+        if X.dim() != 2 or X.shape[0] != rows:
+            raise _lib.TagrecError(f"{name}: expected [{rows}, D], got {tuple(X.shape)}")
+        return int(X.shape[1])
+
+    def spmm(self, X, out=None):
+        D = self._chk_x(X, self.shape[1], "spmm X")
+        if out is None:
+            out = torch.empty(self.shape[0], D, dtype=torch.float32, device=X.device)
+        self._chk_x(out, self.shape[0], "spmm out")
+        _lib.check(_lib.load().tagrec_spmm_f32(self._h, _lib.ptr(X), _lib.ptr(out), D, _lib.stream_ptr()), "spmm")
+        return out
+
+    def spmm_norm_acc(self, X, y_raw, inv_norm, acc, acc_scale):
+        D = self._chk_x(X, self.shape[1], "spmm_norm_acc X")
+        self._chk_x(y_raw, self.shape[0], "spmm_norm_acc y_raw")
+        self._chk_x(acc, self.shape[0], "spmm_norm_acc acc")
+        _lib.require_gpu_tensor(inv_norm, torch.float32, "inv_norm")
+        if inv_norm.numel() != self.shape[0] or acc.shape[1] != D or y_raw.shape[1] != D:
+            raise _lib.TagrecError("spmm_norm_acc: shape mismatch")
+        _lib.check(_lib.load().tagrec_spmm_norm_acc_f32(self._h, _lib.ptr(X), _lib.ptr(y_raw), _lib.ptr(inv_norm),
+                                                        _lib.ptr(acc), float(acc_scale), D, _lib.stream_ptr()),
+                   "spmm_norm_acc")
+
+    def spmm_normbwd(self, g_in, x_raw, inv_norm, dz, d_scale, g_out):
+        D = self._chk_x(g_in, self.shape[1], "spmm_normbwd g_in")
+        for t, nm in ((x_raw, "x_raw"), (dz, "dz"), (g_out, "g_out")):
+            if self._chk_x(t, self.shape[0], "spmm_normbwd " + nm) != D:
+                raise _lib.TagrecError("spmm_normbwd: width mismatch on " + nm)
+        _lib.check(_lib.load().tagrec_spmm_normbwd_f32(self._h, _lib.ptr(g_in), _lib.ptr(x_raw), _lib.ptr(inv_norm),
+                                                       _lib.ptr(dz), float(d_scale), _lib.ptr(g_out), D,
+                                                       _lib.stream_ptr()), "spmm_normbwd")
+
+    def spmm_axpy(self, g_in, b, b_scale, g_out):
+        D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")
+        for t, nm in ((b, "b"), (g_out, "g_out")):
+            if self._chk_x(t, self.shape[0], "spmm_axpy " + nm) != D:
+                raise _lib.TagrecError("spmm_axpy: width mismatch on " + nm)
+        _lib.check(_lib.load().tagrec_spmm_axpy_f32(self._h, _lib.ptr(g_in), _lib.ptr(b), float(b_scale),
+                                                    _lib.ptr(g_out), D, _lib.stream_ptr()), "spmm_axpy")
+
+
+def creat_adj(data, use_tag, norm_type, split_adj_k, device):
+    """Same name, arguments and result convention as the reference's `creat_adj`
+    (adj.py:38-46): one `Graph`, or a list of `split_adj_k` row-fold Graphs."""
+    if use_tag:
+        rowptr, col, val, n = block_adjacency_host(data.ui_adj, data.ut_adj, data.it_adj)
+    else:
+        rowptr, col, val, n = block_adjacency_host(data.ui_adj)
+    rowptr, col, val = normalise_host(rowptr, col, val, n, norm_type)
+    sym = norm_type in ("bi_norm", "plain")
+    if split_adj_k < 2:
+        return Graph.from_host(rowptr, col, val, (n, n), device, symmetric=sym)
+    out = []
+    for lo, hi in fold_bounds(n, split_adj_k):
+        a, b = int(rowptr[lo]), int(rowptr[hi])
+        out.append(Graph.from_host(rowptr[lo:hi + 1] - a, col[a:b], val[a:b], (hi - lo, n), device))
+    return out

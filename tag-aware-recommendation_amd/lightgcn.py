@@ -1,0 +1,236 @@
+"""LightGCN behind the reference's model surface (/root/reference/model/lightgcn.py).
+
+    LightGCN(data)            ctor reads data.num / data.ui_adj[/ut_adj/it_adj] and the config   (:11-35)
+    .forward()                -> tuple(user_emb, item_emb[, tag_emb])                              (:49-63)
+    .loss(batch[B,3])         -> (mul_loss, reg * l2reg_loss on EGO rows), both differentiable     (:68-82)
+    .predict_rating(users)    -> sigmoid(U_b I^T), [b, n_item]                                     (:84-89)
+    .state_dict()             keys embed.0 / embed.1 [/ embed.2], as the reference's ParameterList
+
+Differences in mechanism, not in results:
+  * the per-type tables are row slices of ONE contiguous N x D parameter (`table`), so the
+    `torch.cat` / `torch.split` copies of :52,62 disappear and Adam is one launch;
+  * each layer is one fused HIP kernel (SpMM + L2-normalise + running layer mean), and the whole
+    backward is hand-derived: BPR scatter, then one fused SpMM + normalise-backward per layer.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, help as H
+from .config import CFG as _GLOBAL_CFG
+from .graph import Graph, creat_adj
+
+
+def xavier_tables(num_list, dim, device):
+    """`_init_weight` (lightgcn.py:37-47): xavier_uniform_ per table, in order, drawn from
+    torch's CPU generator so a seeded run reproduces the reference's initial values."""
+    parts = []
+    for n in num_list:
+        t = torch.empty(n, dim)
+        nn.init.xavier_uniform_(t)
+        parts.append(t)
+    return torch.cat(parts, dim=0).to(device)
+
+
+def propagate_forward(graph, x0, n_layer):
+    """x0 -> (out, raws, invs): out = mean(x0, z1..zL), raws[k] = A^(k+1) x0 (un-normalised),
+    invs[k][r] = 1/max(||raws[k][r]||, 1e-12).  One fused kernel per layer."""
+    s = 1.0 / (n_layer + 1)
+    out = x0 * s
+    raws, invs = [], []
+    x = x0
+    for _ in range(n_layer):
+        y = torch.empty_like(x0)
+        inv = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
+        graph.spmm_norm_acc(x, y, inv, out, s)
+        raws.append(y)
+        invs.append(inv)
+        x = y
+    return out, raws, invs
+
+
+def propagate_backward(graph_t, d_out, raws, invs):
+    """Gradient of `propagate_forward` w.r.t. x0 given d_out (dense [N,D]).
+    G^L = nb(X^L);  G^k = A^T G^(k+1) + nb(X^k);  G^0 = A^T G^1 + s*d_out,  nb = normalise-backward of s*d_out."""
+    L = len(raws)
+    s = 1.0 / (L + 1)
+    if L == 0:
+        return d_out.clone()
+    n, D = d_out.shape
+    lib = _lib.load()
+    g = torch.empty_like(d_out)
+    _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(raws[L - 1]), _lib.ptr(invs[L - 1]), _lib.ptr(d_out), D, s,
+                                          _lib.ptr(g), 0, n, D, _lib.stream_ptr()), "rownorm_bwd")
+    for k in range(L - 2, -1, -1):
+        gn = torch.empty_like(d_out)
+        graph_t.spmm_normbwd(g, raws[k], invs[k], d_out, s, gn)
+        g = gn
+    g0 = torch.empty_like(d_out)
+    graph_t.spmm_axpy(g, d_out, s, g0)
+    return g0
+
+
+class _Propagate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, graph, n_layer):
+        out, raws, invs = propagate_forward(graph, table.detach(), n_layer)
+        ctx.graph, ctx.raws, ctx.invs = graph, raws, invs
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        g0 = propagate_backward(ctx.graph.transpose(), d_out.contiguous(), ctx.raws, ctx.invs)
+        ctx.raws = ctx.invs = None
+        return g0, None, None
+
+
+class _PropagateBprLoss(torch.autograd.Function):
+    """table -> [mul_loss, l2reg_loss(ego rows)] in one autograd node."""
+
+    @staticmethod
+    def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active):
+        x0 = table.detach()
+        out, raws, invs = propagate_forward(graph, x0, n_layer)
+        B, D = trip.shape[0], x0.shape[1]
+        coef = torch.empty(B, dtype=torch.float32, device=x0.device)
+        partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=x0.device)
+        res = torch.empty(2, dtype=torch.float32, device=x0.device)
+        U, I = out[:n_user], out[n_user:n_user + n_item]
+        Ue, Ie = x0[:n_user], x0[n_user:n_user + n_item]
+        _lib.check(_lib.load().tagrec_bpr_fwd_f32(_lib.ptr(U), _lib.ptr(I), D, D, _lib.ptr(Ue), _lib.ptr(Ie), D, D,
+                                                  _lib.ptr(trip), B, loss_kind, _lib.ptr(coef), _lib.ptr(partials),
+                                                  _lib.ptr(res), _lib.stream_ptr()), "bpr_fwd")
+        ctx.graph, ctx.raws, ctx.invs = graph, raws, invs
+        ctx.out, ctx.x0, ctx.trip, ctx.coef = out, x0, trip, coef
+        ctx.n_user, ctx.n_item, ctx.reg_active = n_user, n_item, reg_active
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out, x0, trip = ctx.out, ctx.x0, ctx.trip
+        nu, ni, D, B = ctx.n_user, ctx.n_item, x0.shape[1], trip.shape[0]
+        lib = _lib.load()
+        d_out = torch.zeros_like(out)
+        null = _lib.c_void_p(0)
+        U, I = out[:nu], out[nu:nu + ni]
+        _lib.check(lib.tagrec_bpr_bwd_f32(_lib.ptr(U), _lib.ptr(I), D, D, null, null, 0, 0, _lib.ptr(trip), B,
+                                          _lib.ptr(ctx.coef), _lib.ptr(g), 1.0,
+                                          _lib.ptr(d_out[:nu]), _lib.ptr(d_out[nu:nu + ni]), null, null,
+                                          _lib.stream_ptr()), "bpr_bwd")
+        g0 = propagate_backward(ctx.graph.transpose(), d_out, ctx.raws, ctx.invs)
+        # L2 term on the ego rows: added after the propagation hop has written g0
+        if ctx.reg_active:
+            Ue, Ie = x0[:nu], x0[nu:nu + ni]
+            _lib.check(lib.tagrec_bpr_bwd_f32(_lib.ptr(U), _lib.ptr(I), D, D, _lib.ptr(Ue), _lib.ptr(Ie), D, D,
+                                              _lib.ptr(trip), B, _lib.ptr(ctx.coef), _lib.ptr(g), 1.0,
+                                              null, null, _lib.ptr(g0[:nu]), _lib.ptr(g0[nu:nu + ni]),
+                                              _lib.stream_ptr()), "bpr_bwd(reg)")
+        ctx.raws = ctx.invs = ctx.out = None
+        return g0, None, None, None, None, None, None, None
+
+
+class LightGCN(nn.Module):
+    def __init__(self, data, args=None, config=None, graph=None):
+        super().__init__()
+        self._config(config if config is not None else _GLOBAL_CFG)
+        if self.device.type != "cuda":
+            raise _lib.TagrecError("LightGCN: tagrec_amd needs a GPU device (no CPU path)")
+        _lib.load()
+        self.num_list = [data.num["user"], data.num["item"]] + ([data.num["tag"]] if self.use_tag else [])
+        self.norm_adj = graph if graph is not None else creat_adj(data, self.use_tag, self.norm_type,
+                                                                  self.split_adj_k, self.device)
+        self.table = nn.Parameter(xavier_tables(self.num_list, self.dim_latent, self.device))
+        self._offsets = [0]
+        for n in self.num_list:
+            self._offsets.append(self._offsets[-1] + n)
+        self._eval_cache = None
+        self._register_state_dict_hook(_split_table_hook)
+        self._register_load_state_dict_pre_hook(_merge_table_hook, with_module=True)
+
+    def _config(self, config):
+        self.dim_latent = config["dim_latent"]
+        self.num_layer = len(config["dim_layer_list"])   # only the LENGTH matters (lightgcn.py:27)
+        self.device = torch.device(config["device"])
+        self.norm_type = config["norm_type"]
+        self.split_adj_k = config["split_adj_k"]
+        self.reg = config["reg"]
+        self.loss_func = config["mul_loss_func"]
+        self.use_tag = config["use_tag"]
+        self.message_drop_list = config["message_drop_list"]
+        self.node_drop = config["node_drop"]
+
+    # ---- reference attribute names -------------------------------------------------------------
+    @property
+    def embed(self):
+        return [self.table[a:b] for a, b in zip(self._offsets[:-1], self._offsets[1:])]
+
+    def get_ego_embed(self):
+        return self.embed
+
+    def _fused_ok(self):
+        drop = self.training and any(p > 0 for p in self.message_drop_list[:self.num_layer])
+        return isinstance(self.norm_adj, Graph) and not drop
+
+    def _graph(self):
+        return H.node_drop(self.norm_adj, self.node_drop, self.training)
+
+    def _propagate(self):
+        graph = self._graph()
+        if self._fused_ok():
+            return _Propagate.apply(self.table, graph, self.num_layer)
+        # operator-by-operator path (row folds / message dropout), same order as lightgcn.py:52-60
+        x = self.table
+        layers = [x]
+        for k in range(self.num_layer):
+            x = H.split_mm(graph, x)
+            x = torch.nn.functional.dropout(x, p=self.message_drop_list[k], training=self.training)
+            layers.append(H.normalize_rows(x))
+        return torch.mean(torch.stack(layers, dim=1), dim=1)
+
+    def forward(self):
+        out = self._propagate()
+        return tuple(out[a:b] for a, b in zip(self._offsets[:-1], self._offsets[1:]))
+
+    def loss(self, batch_data):
+        batch_data = batch_data.to(self.device, torch.int64).contiguous()
+        nu, ni = self.num_list[0], self.num_list[1]
+        if self._fused_ok():
+            res = _PropagateBprLoss.apply(self.table, self._graph(), self.num_layer, nu, ni, batch_data,
+                                          H.loss_kind_id(self.loss_func), self.reg != 0)
+            return res[0], self.reg * res[1]
+        all_users, all_items = self.forward()[:2]
+        ego = self.embed
+        loss, reg_loss = H.triplet_loss(all_users, all_items, ego[0], ego[1], batch_data, self.loss_func)
+        return loss, self.reg * reg_loss
+
+    def train(self, mode=True):
+        self._eval_cache = None          # parameters may change once training resumes
+        return super().train(mode)
+
+    def predict_rating(self, users):
+        """The reference re-runs forward() for every 512-user batch (lightgcn.py:85).  In eval mode the
+        propagated tables are computed once and reused until `train()` is called again (same values,
+        fewer propagations); in training mode every call propagates, as the reference does."""
+        if self.training or self._eval_cache is None:
+            with torch.no_grad():
+                all_users, all_items = self.forward()[:2]
+            if not self.training:
+                self._eval_cache = (all_users, all_items)
+        else:
+            all_users, all_items = self._eval_cache
+        users = users.to(self.device)
+        return torch.sigmoid(torch.matmul(all_users[users], all_items.t()))
+
+
+def _split_table_hook(module, state_dict, prefix, local_metadata):
+    table = state_dict.pop(prefix + "table")
+    for k, (a, b) in enumerate(zip(module._offsets[:-1], module._offsets[1:])):
+        state_dict[f"{prefix}embed.{k}"] = table[a:b]
+    return state_dict
+
+
+def _merge_table_hook(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    keys = [f"{prefix}embed.{k}" for k in range(len(module.num_list))]
+    module._eval_cache = None
+    if all(k in state_dict for k in keys):
+        state_dict[prefix + "table"] = torch.cat([state_dict.pop(k) for k in keys], dim=0)

@@ -1,0 +1,146 @@
+"""The training step surface of /root/reference/training/basic_train.py, plus the
+fused Adam that replaces `torch.optim.Adam` (com.py:14,25,69).
+
+    epoch_training(training_data, loss_func, opt) -> list[float]      basic_train.py:10-30
+    Basic_train(train_data, loss_func, opt, test, args).run(model)    basic_train.py:50-85
+    Early_stop                                                         training/early_stop.py:8-41
+    Adam(params, lr)   zero_grad()/step()                              torch.optim.Adam defaults
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import CFG as _GLOBAL_CFG
+
+
+class Adam:
+    """torch.optim.Adam (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) as one fused
+    HIP pass per parameter tensor.  Same zero_grad()/step() protocol, so it drops into
+    `epoch_training` where the reference passes a torch optimizer."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("Adam: empty parameter list")
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.state = {}
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load()
+        self.step_count += 1
+        for p in self.params:
+            if p.grad is None:
+                continue
+            _lib.require_gpu_tensor(p.data, torch.float32, "Adam parameter")
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            st = self.state.get(id(p))
+            if st is None:
+                st = self.state[id(p)] = {"m": torch.zeros_like(p.data), "v": torch.zeros_like(p.data), "t": 0}
+            st["t"] += 1
+            _lib.check(lib.tagrec_adam_f32(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
+                                           p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, st["t"],
+                                           _lib.stream_ptr()), "adam")
+
+
+def epoch_training(training_data, loss_func, opt, verbose=True):
+    """One pass over `training_data.mini_batch()` (basic_train.py:10-30): per batch the loss parts,
+    their sum, zero_grad / backward / step.  Returns the per-batch totals as floats.
+    The reference synchronises twice per step to read the losses (:16,27); here the parts stay on
+    the device and are read back once at the end of the epoch -- same numbers, one sync."""
+    parts_dev = []
+    training_data.reset()
+    for data in training_data.mini_batch():
+        lossx = loss_func(data)
+        parts_dev.append(torch.stack([x.detach() for x in lossx]))
+        loss = sum(lossx)
+        if isinstance(opt, list):
+            [op.zero_grad() for op in opt]
+            loss.backward()
+            [op.step() for op in opt]
+        else:
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+    if not parts_dev:
+        return []
+    parts = torch.stack(parts_dev).cpu().numpy()
+    if verbose:
+        print(f"[avg_loss of each part]:{list(parts.sum(0))}")
+    # float32 sum of the parts, as `sum(lossx)` computes it on the device
+    return [float(np.float32(sum(np.float32(v) for v in row))) for row in parts]
+
+
+class Early_stop:
+    """training/early_stop.py:8-41: track the best `key` metric (first entry of a list metric),
+    save `state_dict` on improvement, stop after `patient_epoch` non-improving evaluations."""
+
+    def __init__(self, args=None, config=None):
+        cfg = config if config is not None else _GLOBAL_CFG
+        self.best_value = None
+        self.count_step = 0
+        self.best_result = None
+        self.best_epoch = 0
+        self.patient_step = cfg["patient_epoch"]
+        out_dir = getattr(args, "out_dir", None)
+        self.save_path = f"{out_dir}/model.pth.tar" if out_dir else None
+        self.key = cfg["early_stop_key"]
+        self.higher = self.key in ("precision", "recall", "ndcg")
+
+    def __call__(self, model, cur_results, epoch):
+        cur = cur_results[self.key]
+        cur = cur[0] if isinstance(cur, (list, tuple, np.ndarray)) else cur
+        better = self.best_value is None or (cur > self.best_value if self.higher else cur < self.best_value)
+        if better:
+            self.best_value, self.count_step = cur, 0
+            if self.save_path:
+                os.makedirs(os.path.dirname(self.save_path), exist_ok=True)
+                torch.save(model.state_dict(), self.save_path)
+            self.best_result, self.best_epoch = cur_results, epoch
+        else:
+            self.count_step += 1
+        return self.count_step > self.patient_step
+
+
+class Basic_train:
+    """basic_train.py:50-85: epochs x phases (phase i = train_data[i], loss_func[i], opt[i]),
+    evaluation every `test_interval` epochs, early stop."""
+
+    def __init__(self, train_data, loss_func, opt, test, args=None, config=None):
+        self.cfg = config if config is not None else _GLOBAL_CFG
+        self.train_sphase = len(train_data)
+        self.train_data, self.loss_func, self.opt, self.test, self.args = train_data, loss_func, opt, test, args
+        self.early_stop = Early_stop(args, self.cfg)
+
+    def run(self, model, verbose=True):
+        history = []
+        for ep in range(self.cfg["epochs"]):
+            model.train()
+            for i in range(self.train_sphase):
+                start = time.time()
+                loss_list = epoch_training(self.train_data[i], self.loss_func[i], self.opt[i], verbose=verbose)
+                if verbose:
+                    print(f"[Epoch:{ep}][Time:{(time.time() - start) / 60:.2}]:"
+                          f"avg_loss_{i} :{sum(loss_list) / len(loss_list):.5}")
+                history.append((ep, i, loss_list))
+            if self.test is not None and ep % self.cfg["test_interval"] == 0:
+                results = self.test.run(model)
+                if verbose:
+                    print(f"[Epoch {ep}] results: {results}")
+                if self.early_stop(model, results, ep):
+                    if verbose:
+                        print(f"early stop trigger at epoch {ep}")
+                    break
+        return history

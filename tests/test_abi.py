@@ -1,0 +1,91 @@
+"""CPU-only: the C-ABI library loads and exports exactly what include/tagrec.h declares;
+host-side logic (adjacency build, producer protocol, config defaults) against the golden vectors."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, blocks_from_fixture
+
+import tagrec_amd as T
+from tagrec_amd import graph as G
+from tagrec_amd.synth import Coo
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "tagrec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tagrec_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = T._lib.load()
+    declared = _header_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tagrec.h but not exported"
+    assert sorted(T._lib.exported_symbols()) == declared, "ctypes table and header disagree"
+    assert lib.tagrec_abi_version() == 1
+
+
+def test_missing_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ds = T.synth.make_cf_dataset(20, 15, 80, seed=0)
+    with pytest.raises(T.TagrecError):
+        T.LightGCN(ds, config=T.get_config("lightgcn", use_tag=False, device="cpu"))
+    with pytest.raises(T.TagrecError):
+        T.Graph(torch.zeros(3, dtype=torch.int64), torch.zeros(0, dtype=torch.int32), torch.zeros(0), (2, 2))
+
+
+def _coo(block):
+    r, c, v, shape = block
+    return Coo(np.asarray(r), np.asarray(c), np.asarray(v), shape)
+
+
+@pytest.mark.parametrize("use_tag", [0, 1])
+@pytest.mark.parametrize("norm", ["bi_norm", "ngcf", "si_norm", "si_norm_self", "plain"])
+def test_host_adjacency_bit_exact_vs_reference(golden, use_tag, norm):
+    fx = golden("adj_toy")
+    ui, ut, it = blocks_from_fixture(fx, use_tag)
+    if use_tag:
+        rowptr, col, val, n = G.block_adjacency_host(_coo(ui), _coo(ut), _coo(it))
+    else:
+        rowptr, col, val, n = G.block_adjacency_host(_coo(ui))
+    rowptr, col, val = G.normalise_host(rowptr, col, val, n, norm)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    assert np.array_equal(np.stack([rows, col.astype(np.int64)]), fx[f"{norm}_{use_tag}_idx"])
+    assert np.array_equal(val, fx[f"{norm}_{use_tag}_val"])
+
+
+def test_fold_bounds_match_split_sp_mat(golden):
+    fx = golden("adj_toy")
+    n = int(fx["n_user"] + fx["n_item"] + fx["n_tag"])
+    bounds = G.fold_bounds(n, 3)
+    assert [hi - lo for lo, hi in bounds] == [int(fx[f"fold3_{k}_shape"][0]) for k in range(3)]
+    assert G.fold_bounds(10, 1) == [(0, 10)]
+
+
+def test_mini_batch_protocol(golden):
+    fx = golden("producer")
+    for key in (k for k in fx if k.startswith("mb_")):
+        _, n, B = key.split("_")
+        prod = T.Fixed_training_data([np.arange(int(n))[:, None].repeat(3, 1)], int(B), "cpu")
+        prod.reset()
+        got = [(int(b[0, 0]), int(b[-1, 0]) + 1) for b in prod.mini_batch()]
+        assert got == [tuple(r) for r in fx[key].tolist()], key
+
+
+def test_config_defaults_match_reference():
+    cfg = T.get_config("lightgcn")
+    assert (cfg["train_batch"], cfg["test_batch"], cfg["lr"], cfg["reg"], cfg["dim_latent"]) == (512, 512, 0.01, 0.0, 64)
+    assert cfg["dim_layer_list"] == [64, 32, 16] and cfg["topks"] == [10, 20] and cfg["seed"] == 2020
+    assert cfg["mul_loss_func"] == "softplus" and cfg["norm_type"] == "bi_norm"
+    n = T.get_config("ngcf")
+    assert (n["mul_loss_func"], n["norm_type"], n["agg_type"]) == ("logsigmoid", "ngcf", "bi_agg")
+    t = T.get_config("tgcn")
+    assert (t["neighbor_k"], t["dim_atten"], t["num_bit_conv"], t["num_vec_conv"], t["margin"]) == (25, 32, 32, 8, 1)
+    with pytest.raises(KeyError):
+        T.get_config("kgat")

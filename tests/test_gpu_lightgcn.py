@@ -1,0 +1,236 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle and the reference's golden vectors.
+
+Tolerances (fp32, summation order differs from torch's CPU CSR loop):
+  activations / SpMM outputs   rtol 1e-5, atol 1e-6
+  loss scalars                  rtol 1e-5
+  gradients                     rtol 1e-3, atol 1e-7 * scale (sums of cancelling terms)
+  parameters after Adam         atol 2e-4 (= 2 % of lr): Adam maps g -> lr*g/(|g|+1e-8), which amplifies
+                                last-bit differences of near-zero gradients (see test_oracle_golden)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import blocks_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+import tagrec_amd as T
+from tagrec_amd import graph as G
+from tagrec_amd import help as H
+from tagrec_amd.synth import Coo
+from oracle import adj as oadj
+from oracle import models as om
+
+DEV = torch.device("cuda:0")
+
+
+def _ds_from_fixture(fx):
+    ds = T.synth.Dataset()
+    use_tag = int(fx["use_tag"]) if "use_tag" in fx else 1
+    ui, ut, it = blocks_from_fixture(fx, use_tag)
+    ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"])}
+    ds.ui_adj = Coo(*ui)
+    if use_tag:
+        ds.num["tag"] = int(fx["n_tag"])
+        ds.ut_adj, ds.it_adj = Coo(*ut), Coo(*it)
+    return ds
+
+
+def _oracle_csr(fx, norm=None, use_tag=None):
+    use_tag = int(fx["use_tag"]) if use_tag is None else use_tag
+    norm = str(fx["norm_type"]) if norm is None else norm
+    return oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, use_tag)), norm)
+
+
+def _graph(csr, symmetric=False):
+    return T.Graph.from_host(csr.rowptr, csr.col, csr.val, csr.shape, DEV, symmetric=symmetric)
+
+
+def _model(fx, name="lightgcn"):
+    cfg = T.get_config(name, use_tag=bool(int(fx["use_tag"])), dim_layer_list=[int(x) for x in fx["layers"]],
+                       dim_latent=int(fx["D"]), reg=float(fx["reg"]), device=DEV)
+    m = T.LightGCN(_ds_from_fixture(fx), config=cfg)
+    sd = {k[5:]: torch.from_numpy(fx[k]) for k in fx if k.startswith("init.")}
+    m.load_state_dict(sd)
+    return m
+
+
+# ------------------------------------------------------------------ K1 SpMM
+@pytest.mark.parametrize("D", [64, 32, 16, 128, 256, 10, 100, 4])
+@pytest.mark.parametrize("norm", ["bi_norm", "ngcf"])
+def test_spmm_matches_oracle(golden, D, norm):
+    fx = golden("adj_toy")
+    csr = _oracle_csr(fx, norm, 1)
+    g = _graph(csr)
+    torch.manual_seed(D)
+    X = torch.randn(csr.shape[1], D)
+    want = torch.sparse.mm(om.csr_to_torch(csr), X)
+    got = g.spmm(X.to(DEV)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    # transpose (backward operand)
+    want_t = torch.sparse.mm(om.csr_to_torch(csr.transpose()), X)
+    got_t = g.transpose().spmm(X.to(DEV)).cpu()
+    np.testing.assert_allclose(got_t.numpy(), want_t.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _star_graph(n, hub_deg, rng):
+    """Rows of every length class: empty rows, short rows, a hub beyond the long-row threshold."""
+    rows = [np.zeros(hub_deg, np.int64), rng.randint(1, n, size=4 * n)]
+    cols = [rng.choice(n, hub_deg, replace=False), rng.randint(0, n, size=4 * n)]
+    rows.append(np.full(1500, 7, np.int64)); cols.append(rng.choice(n, 1500, replace=False))   # 1024 < deg < 2*1024
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    keep = r != 5                                       # row 5 stays empty
+    v = rng.rand(len(r)).astype(np.float32)
+    return oadj.coo_to_csr(r[keep], c[keep], v[keep], (n, n))
+
+
+@pytest.mark.parametrize("D", [64, 128, 32])
+def test_spmm_long_rows_and_empty_rows(D):
+    rng = np.random.RandomState(0)
+    csr = _star_graph(6000, 5000, rng)
+    g = _graph(csr)
+    info = g.info()
+    assert info["n_long_rows"] == 2 and info["n_chunks"] == 10 + 3
+    X = torch.randn(6000, D, generator=torch.Generator().manual_seed(1))
+    want = torch.sparse.mm(om.csr_to_torch(csr), X)
+    got = g.spmm(X.to(DEV)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=1e-4)
+    assert torch.all(got[5] == 0)
+    # deterministic: the chunked reduction has a fixed order
+    again = g.spmm(X.to(DEV)).cpu()
+    assert torch.equal(got, again)
+
+
+def test_spmm_rejects_bad_arguments():
+    csr = _star_graph(100, 10, np.random.RandomState(1))
+    g = _graph(csr)
+    with pytest.raises(T.TagrecError):
+        g.spmm(torch.randn(100, 64))                       # CPU tensor
+    with pytest.raises(T.TagrecError):
+        g.spmm(torch.randn(99, 64, device=DEV))            # wrong rows
+    with pytest.raises(T.TagrecError):
+        g.spmm(torch.randn(100, 600, device=DEV))          # width beyond the scalar kernel
+    x = torch.randn(100, 64, device=DEV)
+    with pytest.raises(T.TagrecError):
+        g.spmm(x, out=x)                                   # aliasing
+
+
+# ------------------------------------------------------------------ fused layers vs golden
+@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d32"])
+def test_lightgcn_forward_golden(golden, name):
+    fx = golden(name)
+    m = _model(fx)
+    m.eval()
+    with torch.no_grad():
+        outs = m.forward()
+    for t, o in enumerate(outs):
+        np.testing.assert_allclose(o.cpu().numpy(), fx[f"out.{t}"], rtol=1e-5, atol=1e-6)
+    # raw per-layer products through the operator
+    x = m.table.detach()
+    for k in range(len(fx["layers"])):
+        x = H.split_mm(m.norm_adj, x)
+        np.testing.assert_allclose(x.cpu().numpy(), fx[f"raw.{k}"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d32"])
+def test_lightgcn_loss_and_grads_golden(golden, name):
+    fx = golden(name)
+    m = _model(fx)
+    m.train()
+    lossx = m.loss(torch.from_numpy(fx["batches"][0]).to(DEV))
+    np.testing.assert_allclose([float(v) for v in lossx], fx["loss_parts"], rtol=1e-5, atol=1e-8)
+    sum(lossx).backward()
+    want = np.concatenate([fx[f"grad.embed.{t}"] for t in range(len(m.num_list))])
+    got = m.table.grad.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-7 * np.abs(want).max() / 1e-4)
+
+
+@pytest.mark.parametrize("fused_opt", [True, False])
+@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med"])
+def test_lightgcn_adam_steps_golden(golden, name, fused_opt):
+    fx = golden(name)
+    for n_steps in (1, 3):
+        m = _model(fx)
+        m.train()
+        opt = T.Adam(m.parameters(), lr=float(fx["lr"])) if fused_opt else torch.optim.Adam(m.parameters(), lr=float(fx["lr"]))
+        prod = T.Fixed_training_data([np.concatenate(fx["batches"][:n_steps])], fx["batches"].shape[1], DEV)
+        # Fixed_training_data + the tail rule would merge batches; drive the step surface batch by batch
+        prod.mini_batch = lambda: iter([torch.from_numpy(b).to(DEV) for b in fx["batches"][:n_steps]])
+        losses = T.epoch_training(prod, m.loss, opt, verbose=False)
+        np.testing.assert_allclose(losses, fx[f"step{n_steps}.losses"], rtol=2e-5)
+        sd = m.state_dict()
+        for t in range(len(m.num_list)):
+            got, want = sd[f"embed.{t}"].cpu().numpy(), fx[f"step{n_steps}.embed.{t}"]
+            assert np.abs(got - want).max() <= 2e-4
+            assert np.mean(np.abs(got - want) <= 2e-5) >= 0.995
+
+
+def test_lightgcn_unfused_path_matches_fused(golden):
+    """Row folds (split_adj_k) go operator by operator through autograd; same numbers."""
+    fx = golden("lightgcn_toy")
+    m = _model(fx)
+    cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64, 64], reg=float(fx["reg"]), device=DEV, split_adj_k=3)
+    m2 = T.LightGCN(_ds_from_fixture(fx), config=cfg)
+    m2.load_state_dict(m.state_dict())
+    assert isinstance(m2.norm_adj, list) and len(m2.norm_adj) == 3
+    b = torch.from_numpy(fx["batches"][0]).to(DEV)
+    l1, l2 = m.loss(b), m2.loss(b)
+    np.testing.assert_allclose([float(v) for v in l2], [float(v) for v in l1], rtol=1e-5)
+    sum(l1).backward(); sum(l2).backward()
+    np.testing.assert_allclose(m2.table.grad.cpu().numpy(), m.table.grad.cpu().numpy(), rtol=1e-3, atol=1e-9)
+
+
+def test_predict_rating_golden(golden):
+    fx = golden("lightgcn_toy")
+    m = _model(fx)
+    m.load_state_dict({k[6:]: torch.from_numpy(fx[k]) for k in fx if k.startswith("step3.")})
+    m.eval()
+    r = m.predict_rating(torch.from_numpy(fx["predict.users"]).to(DEV))
+    np.testing.assert_allclose(r.cpu().numpy(), fx["predict.rating"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ operators vs torch autograd
+def test_operator_mul_loss_and_normalize():
+    torch.manual_seed(0)
+    for kind in ("softplus", "logsigmoid"):
+        u, p, n = (torch.randn(77, 48) * 3 for _ in range(3))
+        want_in = [t.clone().requires_grad_() for t in (u, p, n)]
+        want = om.mul_loss(*want_in, kind)
+        want.backward()
+        got_in = [t.clone().to(DEV).requires_grad_() for t in (u, p, n)]
+        got = H.mul_loss(*got_in, kind)
+        got.backward()
+        np.testing.assert_allclose(float(got), float(want), rtol=1e-5)
+        for a, b in zip(got_in, want_in):
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-7)
+    x = torch.randn(50, 40)
+    x[3] = 0                                             # clamped row: eps branch
+    xr = x.clone().requires_grad_()
+    w = torch.randn(50, 40)
+    (torch.nn.functional.normalize(xr, p=2, dim=1) * w).sum().backward()
+    xg = x.clone().to(DEV).requires_grad_()
+    (H.normalize_rows(xg) * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+    big = torch.randn(4, 8) * 60                         # softplus threshold / saturated sigmoid
+    l = H.mul_loss(big.to(DEV), (-big).to(DEV), big.to(DEV), "softplus")
+    np.testing.assert_allclose(float(l), float(om.mul_loss(big, -big, big, "softplus")), rtol=1e-6)
+
+
+def test_adam_kernel_matches_torch():
+    torch.manual_seed(1)
+    p0 = torch.randn(1000, 64)
+    pr = p0.clone().requires_grad_()
+    pg = torch.nn.Parameter(p0.clone().to(DEV))
+    o_ref, o_got = torch.optim.Adam([pr], lr=0.01), T.Adam([pg], lr=0.01)
+    for it in range(5):
+        g = torch.randn(1000, 64) * (10.0 ** -it)
+        pr.grad = g.clone(); pg.grad = g.clone().to(DEV)
+        o_ref.step(); o_got.step()
+    np.testing.assert_allclose(pg.detach().cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-6)
+    odd = torch.nn.Parameter(torch.randn(13, 7).to(DEV))   # length not a multiple of 4: tail kernel
+    ref = odd.detach().cpu().clone().requires_grad_()
+    g = torch.randn(13, 7)
+    odd.grad, ref.grad = g.to(DEV), g.clone()
+    T.Adam([odd], lr=0.1).step(); torch.optim.Adam([ref], lr=0.1).step()
+    np.testing.assert_allclose(odd.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
