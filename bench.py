@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BPR triplets/s of a LightGCN training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scale S]
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): LightGCN, 3 layers, dim 64, synthetic
+1M users x 1M items x 50M edges (N = 2M nodes, nnz = 100M), bi_norm adjacency, BPR softplus loss,
+Adam lr 0.01, train_batch 512 (the reference's default, utility/utils.py:24).  One "step" is what
+`epoch_training` does per mini-batch (training/basic_train.py:14-25): full-graph propagation,
+BPR loss, backward, Adam.  Everything is resident in HBM before the timed region; triplets are
+sampled on the device beforehand (the reference also times its sampler separately).
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the node table, Adam state and
+CSR rows are sharded by row range and every layer all-gathers the shard outputs over RCCL
+(strong scaling of the same graph).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused forward layer
+(`spmm_rows_kernel<16, NORM_ACC>`): algorithmic bytes per launch (SURVEY.md 8d:
+(8+4D) per stored entry + (8+4D) per row + 8D per row for the fused normalise/mean epilogue)
+divided by its mean duration from HIP events recorded on the launch stream inside the timed region.
+`cpu_baseline` times the CPU oracle (PyTorch CPU restatement of the reference path, checked against
+the reference in tests/golden) on a 1/32-scale graph of the same shape and scales by stored entries.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (nodes and edges) for quick runs")
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--big-batch", type=int, default=786432, help="also report triplets/s at this batch (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=3)
+    return ap.parse_args()
+
+
+def spmm_bytes(nnz, n_rows, D, epilogue_row_bytes):
+    return nnz * (8 + 4 * D) + n_rows * (8 + 4 * D) + n_rows * epilogue_row_bytes
+
+
+def cpu_baseline(args, full_nnz):
+    """CPU oracle step time on a 1/32-scale C2-shaped graph, scaled to the full graph by stored entries."""
+    import numpy as np
+    import tagrec_amd as T
+    from oracle import adj as oadj, models as om
+    frac = 32 if args.scale >= 0.5 else 1
+    nu = max(int(1_000_000 * args.scale) // frac, 1000)
+    ne = max(int(50_000_000 * args.scale) // frac, 20000)
+    # the GPU box gives one-GPU jobs a 16-core share of the host; more threads only oversubscribe it
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    torch.set_num_threads(cores)
+    ds = T.synth.make_bipartite_device(nu, nu, ne, seed=11, device="cpu")
+    e = ds.edge_index["train"]
+    rp, c, v, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], nu, nu)
+    A = om.csr_to_torch(oadj.CSR(rp.numpy(), c.numpy(), v.numpy(), (n, n)))
+    torch.manual_seed(2020)
+    tabs = [t.requires_grad_() for t in om.xavier_tables([(nu, args.dim), (nu, args.dim)], 2020)]
+    opt = torch.optim.Adam(tabs, lr=0.01)
+    g = torch.Generator().manual_seed(5)
+    n_warm, n_timed = 1, 4
+    pick = torch.randint(0, e.shape[0], ((n_warm + n_timed) * args.batch,), generator=g)
+    tri = torch.stack([e[pick, 0], e[pick, 1], torch.randint(0, nu, (pick.numel(),), generator=g)], 1)
+    batches = [tri[k * args.batch:(k + 1) * args.batch] for k in range(n_warm + n_timed)]
+    fn = lambda b: om.lightgcn_loss(tabs, A, args.layers, b, 0.0, "softplus")
+    om.adam_epoch(tabs, fn, batches[:n_warm], opt)
+    t0 = time.perf_counter()
+    om.adam_epoch(tabs, fn, batches[n_warm:], opt)
+    dt = (time.perf_counter() - t0) / n_timed
+    nnz_s = int(rp[-1])
+    scaled = dt * full_nnz / nnz_s
+    return {"value": args.batch / scaled, "unit": "triplets/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (torch {torch.__version__} CPU, {cores} threads), LightGCN L={args.layers} D={args.dim} "
+                      f"B={args.batch} on a {nu}x{nu} graph with nnz={nnz_s}: {dt * 1e3:.1f} ms/step measured over {n_timed} steps; "
+                      f"scaled by nnz ratio {full_nnz / nnz_s:.1f} to the full graph"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run with N ranks")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (tagrec_amd has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import tagrec_amd as T
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        from tagrec_amd import dist as TD
+
+    nu = ni = max(int(1_000_000 * args.scale), 2000)
+    ne = max(int(50_000_000 * args.scale), 40000)
+    D, L, B = args.dim, args.layers, args.batch
+    cfg = T.get_config("lightgcn", use_tag=False, dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B)
+
+    t0 = time.perf_counter()
+    ds = T.synth.make_bipartite_device(nu, ni, ne, seed=1, device=dev)
+    e = ds.edge_index["train"]
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], nu, ni)
+    nnz = int(rp[-1])
+    torch.manual_seed(cfg["seed"])
+    if world == 1:
+        G = T.Graph(rp, col, val, (n, n), symmetric=True)
+        model = T.LightGCN(ds, config=cfg, graph=G)
+        timed_graph = G
+    else:
+        model = TD.ShardedLightGCN(ds, cfg, rp, col, val, n)
+        timed_graph = model.graph
+        del rp, col, val
+    opt = T.Adam(model.parameters(), lr=cfg["lr"])
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    prod = T.BPR_training_data(ds, config=cfg, seed=2020)
+    torch.cuda.synchronize()
+    t_sample = time.perf_counter() - t0
+    epoch = prod.all_train_data
+
+    def run_steps(batches):
+        for b in batches:
+            lossx = model.loss(b)
+            opt.zero_grad()
+            sum(lossx).backward()
+            opt.step()
+        return lossx
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(batches):
+        barrier()
+        t = time.perf_counter()
+        last = run_steps(batches)
+        barrier()
+        dt = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
+        return dt, last
+
+    model.train()
+    W, K = args.warmup, args.steps
+    batches = [epoch[k * B:(k + 1) * B] for k in range(W + K)]
+    run_steps(batches[:W])
+    timed_graph.timing = {}
+    dt, last = timed(batches[W:])
+    kernel_ms = timed_graph.timing_ms()
+    timed_graph.timing = None
+    loss_val = [float(x) for x in last]
+
+    extra = {"graph_build_s": round(t_build, 2), "epoch_sampling_s": round(t_sample, 3),
+             "epoch_triplets": int(epoch.shape[0]), "last_loss": loss_val,
+             "edge_layers_per_s": nnz * L * 2 * K / dt}
+    if args.big_batch and epoch.shape[0] >= args.big_batch * 3:
+        BB = args.big_batch
+        bb = [epoch[k * BB:(k + 1) * BB] for k in range(3)]
+        run_steps(bb[:1])
+        dtb, _ = timed(bb[1:])
+        extra[f"triplets_per_s_at_B{BB}"] = 2 * BB / dtb
+        extra[f"ms_per_step_at_B{BB}"] = dtb / 2 * 1e3
+
+    # roofline of the dominant kernel: fused forward layer (local rows of this rank)
+    fwd = kernel_ms.get("spmm_norm_acc", [])
+    n_local_rows = timed_graph.shape[0]
+    local_nnz = timed_graph.nnz
+    alg = spmm_bytes(local_nnz, n_local_rows, D, 8 * D)
+    roof = None
+    if fwd:
+        ms = sum(fwd) / len(fwd)
+        ach = alg / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": f"spmm_rows_kernel<{D // 4}, NORM_ACC> (+ long-row finish)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": alg, "mean_launch_ms": ms, "launches_timed": len(fwd),
+                "other_kernels_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items() if k != "spmm_norm_acc"}}
+        step_bytes = 2 * L * spmm_bytes(nnz, n, D, 0) + L * n * 20 * D + 28 * n * D
+        extra["step_algorithmic_GBps"] = step_bytes / (dt / K) / 1e9 / world
+
+    if rank == 0:
+        out = {"metric": "BPR triplets/sec, LightGCN 3-layer dim64, 1M users x 1M items x 50M edges",
+               "value": K * B / dt, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": W,
+               "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+               "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"C2 LightGCN L={L} D={D} users={nu} items={ni} edges={ne} nnz={nnz} "
+                                      f"train_batch={B} adam lr=0.01 bi_norm softplus",
+                          "train_batch": B, "parallelism": f"row-shard x{world}" if world > 1 else "single"},
+               "roofline": roof, "extra": extra}
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, nnz)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,35 +152,39 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
   }
 }
 
-// ---- short rows: one wave per row --------------------------------------------------------------
+// ---- main kernel: one wave per short row; the FIRST blocks of the grid take the long-row chunks ----
+// (one wave per kChunk entries, partial sums to a slab) so the heavy items start first and the same
+// launch covers every stored entry of the matrix.
+struct LongView {
+  const int32_t* long_rows;
+  const int2* chunk_desc;
+  int64_t n_chunks;
+  float* slab;
+  unsigned chunk_blocks;
+};
+
 template <int LPR, int EPI>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(GraphView g, const float* __restrict__ X,
-                                                                            EpiArgs e) {
+                                                                            EpiArgs e, LongView lv) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (blockIdx.x < lv.chunk_blocks) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (c >= lv.n_chunks) return;
+    const int2 d = lv.chunk_desc[c];
+    const int64_t r = lv.long_rows[d.x];
+    const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
+    const int64_t row_end = g.rowptr[r + 1];
+    const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
+    const float4 acc = gather_rows<LPR>(g, X, start, end, lane);
+    if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[c * LPR + lane] = acc;
+    return;
+  }
+  const int64_t r = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
   if (r >= g.n_rows) return;
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
-  if (end - start > kLongRow) return;  // chunk kernels own this row
+  if (end - start > kLongRow) return;  // chunked above, folded by spmm_finish_kernel
   const float4 acc = gather_rows<LPR>(g, X, start, end, lane);
   row_epilogue<LPR, EPI>(acc, r, lane, e);
-}
-
-// ---- long rows: one wave per kChunk entries, partial sums to a slab ----------------------------
-template <int LPR>
-__global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_chunk_kernel(GraphView g, const float* __restrict__ X,
-                                                                             const int32_t* __restrict__ long_rows,
-                                                                             const int2* __restrict__ chunk_desc,
-                                                                             int64_t n_chunks, float* __restrict__ slab) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (c >= n_chunks) return;
-  const int2 d = chunk_desc[c];
-  const int64_t r = long_rows[d.x];
-  const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
-  const int64_t row_end = g.rowptr[r + 1];
-  const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
-  const float4 acc = gather_rows<LPR>(g, X, start, end, lane);
-  if (lane < LPR) reinterpret_cast<float4*>(slab)[c * LPR + lane] = acc;
 }
 
 template <int LPR, int EPI>
@@ -410,14 +414,14 @@ int launch_vec(const tagrec_graph* g, const float* X, const EpiArgs& e, hipStrea
   const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
   const int threads = kWavesPerBlock * kWave;
   const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  LongView lv{g->long_rows, g->chunk_desc, g->n_chunks, nullptr, 0};
   if (g->n_long > 0) {
     int rc = ensure_slab(g, LPR * 4);
     if (rc != TAGREC_OK) return rc;
-    const unsigned cblocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
-    spmm_chunk_kernel<LPR><<<cblocks, threads, 0, s>>>(gv, X, g->long_rows, g->chunk_desc, g->n_chunks, g->slab);
-    TAGREC_LAUNCH_CHECK();
+    lv.slab = g->slab;
+    lv.chunk_blocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
   }
-  spmm_rows_kernel<LPR, EPI><<<blocks, threads, 0, s>>>(gv, X, e);
+  spmm_rows_kernel<LPR, EPI><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
   TAGREC_LAUNCH_CHECK();
   if (g->n_long > 0) {
     const unsigned fblocks = static_cast<unsigned>((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock);

@@ -161,6 +161,7 @@ class Graph:
             raise _lib.TagrecError("Graph: inconsistent CSR array sizes")
         self.symmetric = bool(symmetric) and self.shape[0] == self.shape[1]
         self._T = None
+        self.timing = None            # set to {} to record (start, end) HIP events per kernel entry point
         self._h = _lib.c_void_p()
         lib = _lib.load()
         with torch.cuda.device(self.val.device):
@@ -214,6 +215,23 @@ class Graph:
         return self._T
 
     # -- raw kernel entry points (no autograd) ---------------------------------------------------
+    def _call(self, name, fn, *args):
+        """Run one library call; when `timing` is a dict, bracket it with events recorded on the
+        stream the kernel is launched on (torch's current stream)."""
+        if self.timing is None:
+            _lib.check(fn(*args), name)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(fn(*args), name)
+        e1.record()
+        self.timing.setdefault(name, []).append((e0, e1))
+
+    def timing_ms(self):
+        """{entry point: [ms per call]} for the events recorded so far (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.timing or {}).items()}
+
     def _chk_x(self, X, rows, name):
         _lib.require_gpu_tensor(X, torch.float32, name)
         if X.dim() != 2 or X.shape[0] != rows:
@@ -225,7 +243,7 @@ class Graph:
         if out is None:
             out = torch.empty(self.shape[0], D, dtype=torch.float32, device=X.device)
         self._chk_x(out, self.shape[0], "spmm out")
-        _lib.check(_lib.load().tagrec_spmm_f32(self._h, _lib.ptr(X), _lib.ptr(out), D, _lib.stream_ptr()), "spmm")
+        self._call("spmm", _lib.load().tagrec_spmm_f32, self._h, _lib.ptr(X), _lib.ptr(out), D, _lib.stream_ptr())
         return out
 
     def spmm_norm_acc(self, X, y_raw, inv_norm, acc, acc_scale):
@@ -235,26 +253,24 @@ class Graph:
         _lib.require_gpu_tensor(inv_norm, torch.float32, "inv_norm")
         if inv_norm.numel() != self.shape[0] or acc.shape[1] != D or y_raw.shape[1] != D:
             raise _lib.TagrecError("spmm_norm_acc: shape mismatch")
-        _lib.check(_lib.load().tagrec_spmm_norm_acc_f32(self._h, _lib.ptr(X), _lib.ptr(y_raw), _lib.ptr(inv_norm),
-                                                        _lib.ptr(acc), float(acc_scale), D, _lib.stream_ptr()),
-                   "spmm_norm_acc")
+        self._call("spmm_norm_acc", _lib.load().tagrec_spmm_norm_acc_f32, self._h, _lib.ptr(X), _lib.ptr(y_raw),
+                   _lib.ptr(inv_norm), _lib.ptr(acc), float(acc_scale), D, _lib.stream_ptr())
 
     def spmm_normbwd(self, g_in, x_raw, inv_norm, dz, d_scale, g_out):
         D = self._chk_x(g_in, self.shape[1], "spmm_normbwd g_in")
         for t, nm in ((x_raw, "x_raw"), (dz, "dz"), (g_out, "g_out")):
             if self._chk_x(t, self.shape[0], "spmm_normbwd " + nm) != D:
                 raise _lib.TagrecError("spmm_normbwd: width mismatch on " + nm)
-        _lib.check(_lib.load().tagrec_spmm_normbwd_f32(self._h, _lib.ptr(g_in), _lib.ptr(x_raw), _lib.ptr(inv_norm),
-                                                       _lib.ptr(dz), float(d_scale), _lib.ptr(g_out), D,
-                                                       _lib.stream_ptr()), "spmm_normbwd")
+        self._call("spmm_normbwd", _lib.load().tagrec_spmm_normbwd_f32, self._h, _lib.ptr(g_in), _lib.ptr(x_raw),
+                   _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), _lib.ptr(g_out), D, _lib.stream_ptr())
 
     def spmm_axpy(self, g_in, b, b_scale, g_out):
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")
         for t, nm in ((b, "b"), (g_out, "g_out")):
             if self._chk_x(t, self.shape[0], "spmm_axpy " + nm) != D:
                 raise _lib.TagrecError("spmm_axpy: width mismatch on " + nm)
-        _lib.check(_lib.load().tagrec_spmm_axpy_f32(self._h, _lib.ptr(g_in), _lib.ptr(b), float(b_scale),
-                                                    _lib.ptr(g_out), D, _lib.stream_ptr()), "spmm_axpy")
+        self._call("spmm_axpy", _lib.load().tagrec_spmm_axpy_f32, self._h, _lib.ptr(g_in), _lib.ptr(b),
+                   float(b_scale), _lib.ptr(g_out), D, _lib.stream_ptr())
 
 
 def creat_adj(data, use_tag, norm_type, split_adj_k, device):

@@ -131,3 +131,54 @@ def sample_bpr_epoch(ds, seed, shuffle=True):
     if shuffle:
         out = out[rng.permutation(len(out))]
     return out
+
+
+# ---------------------------------------------------------------------------------- device generator
+def make_bipartite_device(n_user, n_item, n_edge, seed, device, item_alpha=0.8, item_cap=100_000,
+                          user_mu=3.5, user_sigma=0.8):
+    """C2/C5-style user-item graph generated ON the GPU: item popularity
+    Zipf(item_alpha) capped at `item_cap` interactions, user activity log-normal(mu, sigma),
+    both rescaled to `n_edge` DISTINCT pairs, every user and item has degree >= 1, ids randomly
+    permuted (so a contiguous row range is a statistically balanced shard).
+    Returns a `Dataset` whose `edge_index['train']` is an int64 [E,2] tensor on `device`
+    (sorted by (user, item)); `user_items` is left empty -- at this size it never visits the host."""
+    import torch
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+
+    wi = torch.arange(1, n_item + 1, device=dev, dtype=torch.float64).pow(-item_alpha)
+    wi = wi / wi.sum()
+    wi = torch.clamp(wi, max=float(item_cap) / float(n_edge))
+    wu = torch.exp(user_mu + user_sigma * torch.randn(n_user, device=dev, dtype=torch.float64, generator=gen))
+    cdf_i = torch.cumsum(wi / wi.sum(), 0)
+    cdf_u = torch.cumsum(wu / wu.sum(), 0)
+    perm_i = torch.randperm(n_item, device=dev, generator=gen)
+
+    def draw(m):
+        u = torch.searchsorted(cdf_u, torch.rand(m, device=dev, dtype=torch.float64, generator=gen)).clamp_(max=n_user - 1)
+        i = torch.searchsorted(cdf_i, torch.rand(m, device=dev, dtype=torch.float64, generator=gen)).clamp_(max=n_item - 1)
+        return u, perm_i[i]
+
+    # degree >= 1 for everyone
+    u0, i0 = draw(n_user + n_item)
+    u0[:n_user] = torch.arange(n_user, device=dev)
+    i0[n_user:] = torch.arange(n_item, device=dev)
+    key = torch.unique(u0 * n_item + i0)
+    base = key
+    while key.numel() < n_edge:
+        m = int((n_edge - key.numel()) * 1.15) + 1024
+        u, i = draw(m)
+        key = torch.unique(torch.cat([key, u * n_item + i]))
+    if key.numel() > n_edge:
+        is_base = torch.isin(key, base)
+        extra = torch.nonzero(~is_base).flatten()
+        drop = extra[torch.randperm(extra.numel(), device=dev, generator=gen)[:key.numel() - n_edge]]
+        keep = torch.ones(key.numel(), dtype=torch.bool, device=dev)
+        keep[drop] = False
+        key = key[keep]
+    ds = Dataset()
+    ds.num = {"user": int(n_user), "item": int(n_item)}
+    u = torch.div(key, n_item, rounding_mode="floor")
+    ds.edge_index = {"train": torch.stack([u, key - u * n_item], dim=1).contiguous()}
+    return ds

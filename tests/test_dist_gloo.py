@@ -1,0 +1,139 @@
+"""World-size-2 (and 3: uneven shards) run of the row-sharded LightGCN host logic on CPU ranks over gloo.
+
+The local kernels are replaced by a CPU test double built from torch ops (`CpuOps` below) -- this
+checks the partitioning, the all-gather / all-reduce plumbing, the batch-row exchange and the
+gradient scatter of tagrec_amd/dist.py against the single-process oracle.  The HIP kernels
+themselves are checked in the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden, blocks_from_fixture
+
+
+class CpuOps:
+    """Test double for tagrec_amd.dist.HipOps (same call signatures, torch CPU arithmetic)."""
+
+    def make_graph(self, rowptr, col, val, shape):
+        return torch.sparse_csr_tensor(rowptr, col.long(), val, size=shape)
+
+    @staticmethod
+    def _nb(x_raw, inv, dz):
+        z = x_raw * inv[:, None]
+        dot = (z * dz).sum(1, keepdim=True)
+        dot = torch.where(inv[:, None] >= 1e12, torch.zeros_like(dot), dot)
+        return inv[:, None] * (dz - z * dot)
+
+    def spmm_norm_acc(self, g, x, y, inv, acc, s):
+        y.copy_(g @ x)
+        den = y.norm(dim=1).clamp_min(1e-12)
+        inv.copy_(1.0 / den)
+        acc.add_(s * y / den[:, None])
+
+    def spmm_normbwd(self, g, g_in, x_raw, inv, dz, s, out):
+        out.copy_(g @ g_in + self._nb(x_raw, inv, s * dz))
+
+    def spmm_axpy(self, g, g_in, b, s, out):
+        out.copy_(g @ g_in + s * b)
+
+    def rownorm_bwd(self, x_raw, inv, dz, s, out):
+        out.copy_(self._nb(x_raw, inv, s * dz))
+
+    def bpr_fwd(self, U, I, Ur, Ir, trip, kind):
+        u, p, n = U[trip[:, 0]], I[trip[:, 1]], I[trip[:, 2]]
+        x = (u * n).sum(1) - (u * p).sum(1)
+        loss = torch.nn.functional.softplus(x).mean() if kind == 0 else -torch.nn.functional.logsigmoid(-x).mean()
+        reg = 0.5 * (Ur[trip[:, 0]].pow(2).sum() + Ir[trip[:, 1]].pow(2).sum() + Ir[trip[:, 2]].pow(2).sum()) / trip.shape[0]
+        return torch.stack([loss, reg]), torch.sigmoid(x)
+
+    def bpr_bwd(self, U, I, Ur, Ir, trip, coef, g, dU, dI, dUr, dIr):
+        B = trip.shape[0]
+        c = (g[0] * coef / B)[:, None]
+        u, p, n = U[trip[:, 0]], I[trip[:, 1]], I[trip[:, 2]]
+        dU.index_add_(0, trip[:, 0], c * (n - p))
+        dI.index_add_(0, trip[:, 1], -c * u)
+        dI.index_add_(0, trip[:, 2], c * u)
+        cr = g[1] / B
+        dUr.index_add_(0, trip[:, 0], cr * Ur[trip[:, 0]])
+        dIr.index_add_(0, trip[:, 1], cr * Ir[trip[:, 1]])
+        dIr.index_add_(0, trip[:, 2], cr * Ir[trip[:, 2]])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tagrec_amd as T
+    from tagrec_amd import dist as TD
+    from oracle import adj as oadj
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        fx = load_golden("lightgcn_toy")
+        csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "bi_norm")
+        cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64, 64], reg=float(fx["reg"]), device="cpu")
+        ds = T.synth.Dataset()
+        ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
+        torch.manual_seed(2020)
+        m = TD.ShardedLightGCN(ds, cfg, torch.from_numpy(csr.rowptr), torch.from_numpy(csr.col),
+                               torch.from_numpy(csr.val), csr.shape[0], ops=CpuOps())
+        # load the fixture's init so the comparison does not depend on the RNG
+        full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)])
+        with torch.no_grad():
+            m.table.zero_()
+            real_hi = min(m.hi, full.shape[0])
+            m.table[:real_hi - m.lo] = full[m.lo:real_hi]
+        opt = torch.optim.Adam(m.parameters(), lr=0.01)
+        losses = []
+        for b in fx["batches"][:3]:
+            lossx = m.loss(torch.from_numpy(b))
+            losses.append([float(x) for x in lossx])
+            opt.zero_grad()
+            sum(lossx).backward()
+            if len(losses) == 1:
+                grad0 = m.all_gather(m.table.grad)[:full.shape[0]].clone()
+            opt.step()
+        table = m.gathered_table()
+        u_out, i_out = m.forward()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, f"w{world}.npz"), losses=np.array(losses), grad0=grad0.numpy(),
+                     table=table.numpy(), u_out=u_out.numpy(), i_out=i_out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_lightgcn_matches_single_process(tmp_path, golden, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / f"w{world}.npz")
+    fx = golden("lightgcn_toy")
+    np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
+    np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=1e-5)
+    want_g = np.concatenate([fx[f"grad.embed.{t}"] for t in range(3)])
+    np.testing.assert_allclose(got["grad0"], want_g, rtol=1e-3, atol=1e-8)
+    want_t = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
+    assert np.abs(got["table"] - want_t).max() <= 2e-4
+
+
+def test_shard_helpers():
+    from tagrec_amd import dist as TD
+    assert TD.shard_rows(82, 2) == (41, 82) and TD.shard_rows(82, 3) == (28, 84) and TD.shard_rows(8, 8) == (1, 8)
+    rp = torch.tensor([0, 2, 2, 5, 6])
+    col = torch.arange(6, dtype=torch.int32)
+    val = torch.arange(6, dtype=torch.float32)
+    a, c, v = TD.local_csr(rp, col, val, 3, 6, 3)          # last shard: one real row + two padding rows
+    assert a.tolist() == [0, 1, 1, 1] and c.tolist() == [5] and v.tolist() == [5.0]
+    a, c, v = TD.local_csr(rp, col, val, 0, 3, 3)
+    assert a.tolist() == [0, 2, 2, 5] and c.tolist() == [0, 1, 2, 3, 4]

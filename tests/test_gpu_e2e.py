@@ -1,0 +1,156 @@
+"""GPU: end-to-end Recall@20 parity at C1 scale, the evaluation path, the device-side producers, and
+size-independent properties of the SpMM at the full C2 size (BASELINE.json configs[1])."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tagrec_amd as T
+from oracle import data as odata
+
+DEV = torch.device("cuda:0")
+
+
+def test_recall_at_20_matches_reference_run(golden):
+    """Same graph, same init (torch CPU seed 2020), same per-epoch triplets (numpy seed 2020+epoch),
+    6 epochs of B=512 Adam steps: Recall@20 within +-1e-3 of the reference's own CPU run
+    (BASELINE.json north_star), loss curve within 1e-3."""
+    fx = golden("e2e_c1_lightgcn")
+    ds = T.synth.make_cf_dataset()
+    assert int(ds.edge_index["train"].astype(np.int64).sum()) == int(fx["edge_checksum"])
+    cfg = T.get_config("lightgcn", use_tag=False, dim_layer_list=[64, 64], device=DEV, train_batch=int(fx["batch"]))
+    torch.manual_seed(2020)
+    model = T.LightGCN(ds, config=cfg)
+    np.testing.assert_allclose(float(model.table.double().sum()), float(fx["init_sum"]), rtol=1e-9)
+    opt = T.Adam(model.parameters(), lr=float(fx["lr"]))
+    epochs = int(fx["epochs"])
+    prod = T.Fixed_training_data([T.synth.sample_bpr_epoch(ds, 2020 + ep) for ep in range(epochs)], cfg["train_batch"], DEV)
+    curve = []
+    for _ in range(epochs):
+        model.train()
+        losses = T.epoch_training(prod, model.loss, opt, verbose=False)
+        curve.append(float(np.mean(losses)))
+    np.testing.assert_allclose(curve, fx["loss_curve"], atol=1e-3)
+    res = T.Basic_test(ds, config=cfg).run(model)
+    assert abs(res["recall"][1] - fx["res.recall"][1]) <= 1e-3, (res["recall"], fx["res.recall"])
+    assert abs(res["recall"][0] - fx["res.recall"][0]) <= 1e-3
+    np.testing.assert_allclose(res["ndcg"], fx["res.ndcg"], atol=2e-3)
+    np.testing.assert_allclose(res["precision"], fx["res.precision"], atol=1e-3)
+    np.testing.assert_allclose(res["hr"], fx["res.hr"], atol=5e-3)
+
+
+class _FixedScores(torch.nn.Module):
+    def __init__(self, rating):
+        super().__init__()
+        self.r = rating
+
+    def predict_rating(self, users):
+        return self.r[users].clone()
+
+
+def test_basic_test_metrics_golden(golden):
+    """Device-side mask -> top-k -> recall/precision/hr/ndcg against the reference's `test_users`
+    output, and the rank-based AUC against a direct pair count."""
+    fx = golden("metrics")
+    nu, ni = fx["rating"].shape
+    ds = T.synth.Dataset()
+    ds.num = {"user": nu, "item": ni}
+    ds.user_items = {"train": {u: fx[f"train.{u}"].tolist() for u in range(nu)},
+                     "test": {u: fx[f"test.{u}"].tolist() for u in range(nu)}}
+    cfg = T.get_config("lightgcn", device=DEV, test_batch=7)
+    res = T.Basic_test(ds, config=cfg).run(_FixedScores(torch.from_numpy(fx["rating"]).to(DEV)))
+    for k in ("recall", "precision", "hr", "ndcg"):
+        np.testing.assert_allclose(res[k], fx["res." + k] / nu, rtol=1e-6, err_msg=k)
+    # AUC: fraction of (test item, other unmasked item) pairs ranked correctly, mean over users
+    auc = []
+    for u in range(nu):
+        r = fx["rating"][u].copy()
+        keep = np.ones(ni, bool); keep[fx[f"train.{u}"]] = False
+        pos = np.zeros(ni, bool); pos[fx[f"test.{u}"]] = True
+        p, n = r[keep & pos], r[keep & ~pos]
+        auc.append(((p[:, None] > n[None, :]).sum() + 0.5 * (p[:, None] == n[None, :]).sum()) / (len(p) * len(n)))
+    np.testing.assert_allclose(res["auc"][0], np.mean(auc), rtol=1e-9)
+
+
+def test_device_bpr_producer_properties():
+    ds = T.synth.make_cf_dataset(300, 200, 6000, seed=5)
+    cfg = T.get_config("lightgcn", device=DEV, train_batch=512)
+    prod = T.BPR_training_data(ds, config=cfg, seed=1)
+    a = prod.all_train_data.cpu().numpy()
+    tr = ds.edge_index["train"]
+    assert a.shape == (len(tr), 3)
+    key = lambda x, y: x.astype(np.int64) * 200 + y
+    assert np.array_equal(np.sort(key(a[:, 0], a[:, 1])), np.sort(key(tr[:, 0], tr[:, 1])))   # a permutation of the edges
+    assert not np.isin(key(a[:, 0], a[:, 2]), key(tr[:, 0], tr[:, 1])).any()                   # negatives are never train items
+    assert a[:, 2].min() >= 0 and a[:, 2].max() < 200
+    prod.reset()
+    b = prod.all_train_data.cpu().numpy()
+    assert not np.array_equal(a, b)                                                            # re-sampled every epoch
+    sizes = [x.shape[0] for x in prod.mini_batch()]
+    assert sizes == [hi - lo for lo, hi in odata.mini_batch_bounds(len(tr), 512)]
+    # negatives are uniform over the non-train items: chi-square-ish check on a dense user
+    u = np.bincount(tr[:, 0]).argmax()
+    draws = np.concatenate([np.asarray(T.BPR_training_data(ds, config=cfg, seed=s).all_train_data.cpu())
+                            for s in range(20)])
+    neg = draws[draws[:, 0] == u][:, 2]
+    free = np.setdiff1d(np.arange(200), tr[tr[:, 0] == u][:, 1])
+    cnt = np.bincount(neg, minlength=200)[free]
+    assert cnt.min() > 0 and cnt.max() < 4 * cnt.mean()
+
+
+@pytest.fixture(scope="module")
+def c2_graph():
+    nu = ni = 1_000_000
+    ds = T.synth.make_bipartite_device(nu, ni, 50_000_000, seed=1, device=DEV)
+    e = ds.edge_index["train"]
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], nu, ni)
+    return T.Graph(rp, col, val, (n, n), symmetric=True), e
+
+
+def test_c2_graph_shape(c2_graph):
+    g, e = c2_graph
+    assert g.shape == (2_000_000, 2_000_000) and g.nnz == 100_000_000
+    assert e.shape == (50_000_000, 2)
+    key = e[:, 0] * 1_000_000 + e[:, 1]
+    assert bool((key[1:] > key[:-1]).all())                                   # distinct pairs
+    deg = g.rowptr[1:] - g.rowptr[:-1]
+    assert int(deg.min()) >= 1 and int(deg[1_000_000:].max()) <= 110_000     # degree >= 1, item cap
+    assert g.info()["n_long_rows"] > 0                                        # the chunked path is exercised
+
+
+def test_c2_spmm_properties(c2_graph):
+    """At full size the oracle is too slow; check what must hold for ANY correct SpMM:
+    linearity, self-adjointness of the symmetric bi_norm matrix, agreement with an independent
+    torch formulation on sampled rows (incl. the longest), run-to-run determinism."""
+    g, _ = c2_graph
+    n, D = g.shape[0], 64
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(n, D, device=DEV, generator=gen)
+    y = torch.randn(n, D, device=DEV, generator=gen)
+    ax, ay = g.spmm(x), g.spmm(y)
+    axy = g.spmm(2.0 * x - 0.5 * y)
+    scale = float(ax.abs().mean())
+    assert float((axy - (2.0 * ax - 0.5 * ay)).abs().max()) <= 2e-5 * max(1.0, scale * 50)
+    lhs, rhs = float((ax.double() * y.double()).sum()), float((x.double() * ay.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * (abs(lhs) + abs(rhs)) + 1e-3
+    deg = g.rowptr[1:] - g.rowptr[:-1]
+    rows = torch.cat([torch.randint(0, n, (200,), device=DEV, generator=gen), torch.topk(deg, 3).indices])
+    for r in rows.tolist():
+        lo, hi = int(g.rowptr[r]), int(g.rowptr[r + 1])
+        want = (g.val[lo:hi, None].double() * x[g.col[lo:hi].long()].double()).sum(0)
+        np.testing.assert_allclose(ax[r].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(ax, g.spmm(x))
+
+
+def test_c2_fused_layer_consistent_with_plain_spmm(c2_graph):
+    g, _ = c2_graph
+    n, D = g.shape[0], 64
+    x = torch.randn(n, D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    y_raw, inv, acc = torch.empty_like(x), torch.empty(n, device=DEV), torch.zeros_like(x)
+    g.spmm_norm_acc(x, y_raw, inv, acc, 0.25)
+    plain = g.spmm(x)
+    assert torch.equal(y_raw, plain)
+    z = torch.nn.functional.normalize(plain, p=2, dim=1)
+    assert float((acc - 0.25 * z).abs().max()) <= 1e-6
+    np.testing.assert_allclose(inv.cpu().numpy(), (1.0 / plain.norm(dim=1).clamp_min(1e-12)).cpu().numpy(), rtol=1e-5)
