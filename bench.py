@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--model", choices=["lightgcn", "ngcf"], default="lightgcn",
+                    help="lightgcn = C2 (headline); ngcf = C3 (same graph, D^-1 A + I, MFMA dense layers)")
     return ap.parse_args()
 
 
@@ -112,18 +114,21 @@ def main():
     nu = ni = max(int(1_000_000 * args.scale), 2000)
     ne = max(int(50_000_000 * args.scale), 40000)
     D, L, B = args.dim, args.layers, args.batch
-    cfg = T.get_config("lightgcn", use_tag=False, dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B)
+    cfg = T.get_config(args.model, use_tag=False, dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B)
+    if args.model == "ngcf" and world > 1:
+        sys.exit("bench.py: the sharded path covers LightGCN (C2/C5); run --model ngcf on one GPU")
 
     t0 = time.perf_counter()
     ds = T.synth.make_bipartite_device(nu, ni, ne, seed=1, device=dev)
     e = ds.edge_index["train"]
-    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], nu, ni)
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], nu, ni, cfg["norm_type"])
     nnz = int(rp[-1])
     torch.manual_seed(cfg["seed"])
     if world == 1:
-        G = T.Graph(rp, col, val, (n, n), symmetric=True)
-        model = T.LightGCN(ds, config=cfg, graph=G)
+        G = T.Graph(rp, col, val, (n, n), symmetric=(cfg["norm_type"] == "bi_norm"))
+        model = (T.LightGCN if args.model == "lightgcn" else T.NGCF)(ds, config=cfg, graph=G)
         timed_graph = G
+        G.transpose()                      # NGCF: build A^T once, outside the timed region
     else:
         model = TD.ShardedLightGCN(ds, cfg, rp, col, val, n)
         timed_graph = model.graph
@@ -186,31 +191,43 @@ def main():
         extra[f"ms_per_step_at_B{BB}"] = dtb / 2 * 1e3
 
     # roofline of the dominant kernel: fused forward layer (local rows of this rank)
-    fwd = kernel_ms.get("spmm_norm_acc", [])
+    dom = "spmm_norm_acc" if args.model == "lightgcn" else "spmm"
+    fwd = kernel_ms.get(dom, [])
     n_local_rows = timed_graph.shape[0]
     local_nnz = timed_graph.nnz
-    alg = spmm_bytes(local_nnz, n_local_rows, D, 8 * D)
+    alg = spmm_bytes(local_nnz, n_local_rows, D, 8 * D if args.model == "lightgcn" else 0)
     roof = None
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_c2_lightgcn.json")
+    if world == 1 and args.scale == 1.0 and D == 64 and args.model == "lightgcn" and os.path.exists(pmc_path):
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction; see profiles/README.md)
+        with open(pmc_path) as f:
+            traffic = json.load(f)["kernels"]["spmm_rows_kernel<16, 1>"]["traffic_bytes_per_launch"]
     if fwd:
         ms = sum(fwd) / len(fwd)
         ach = alg / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": f"spmm_rows_kernel<{D // 4}, NORM_ACC> (+ long-row finish)",
+        roof = {"bound": "hbm", "kernel": f"spmm_rows_kernel<{D // 4}, {'NORM_ACC' if args.model == 'lightgcn' else 'NONE'}> (+ long-row finish)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": alg, "mean_launch_ms": ms, "launches_timed": len(fwd),
-                "other_kernels_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items() if k != "spmm_norm_acc"}}
-        step_bytes = 2 * L * spmm_bytes(nnz, n, D, 0) + L * n * 20 * D + 28 * n * D
-        extra["step_algorithmic_GBps"] = step_bytes / (dt / K) / 1e9 / world
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "mean_launch_ms": ms, "launches_timed": len(fwd),
+                "other_kernels_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items() if k != dom}}
+        if args.model == "lightgcn":
+            step_bytes = 2 * L * spmm_bytes(nnz, n, D, 0) + L * n * 20 * D + 28 * n * D
+            extra["step_algorithmic_GBps"] = step_bytes / (dt / K) / 1e9 / world
+        else:
+            extra["dense_gflop_per_step"] = L * 3 * 2 * 2 * n * D * D / 1e9      # fwd + recompute/dA + dW, two matrices each
 
     if rank == 0:
-        out = {"metric": "BPR triplets/sec, LightGCN 3-layer dim64, 1M users x 1M items x 50M edges",
+        mname = "LightGCN" if args.model == "lightgcn" else "NGCF"
+        out = {"metric": f"BPR triplets/sec, {mname} {L}-layer dim{D}, 1M users x 1M items x 50M edges",
                "value": K * B / dt, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": dt / K * 1e3, "higher_is_better": True,
                "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"C2 LightGCN L={L} D={D} users={nu} items={ni} edges={ne} nnz={nnz} "
-                                      f"train_batch={B} adam lr=0.01 bi_norm softplus",
+               "config": {"workload": f"{'C2' if args.model == 'lightgcn' else 'C3'} {mname} L={L} D={D} users={nu} items={ni} "
+                                      f"edges={ne} nnz={nnz} train_batch={B} adam lr=0.01 {cfg['norm_type']} {cfg['mul_loss_func']}",
                           "train_batch": B, "parallelism": f"row-shard x{world}" if world > 1 else "single"},
                "roofline": roof, "extra": extra}
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and world == 1 and args.model == "lightgcn":
             out["cpu_baseline"] = cpu_baseline(args, nnz)
         else:
             out["cpu_baseline"] = None

@@ -113,6 +113,28 @@ int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, int D,
 int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
                     float lr, float b1, float b2, float eps, int64_t step, void* stream);
 
+/* ---- NGCF layer, dense half (ngcf.py:77-86), exact-fp32 MFMA ------------------------------------------
+ * Given N = A @ X (tagrec_spmm_f32) and W1p = W1 + b1, W2p = W2 + b2 (row-major [Din, Dout]; the
+ * reference adds the 1 x Dout bias to the weight matrix, ngcf.py:78,82):
+ *   fwd : Xp = LeakyReLU_0.2((N + X) W1p) + LeakyReLU_0.2((N * X) W2p);  inv_norm = 1/max(||Xp||, 1e-12);
+ *         Z  = Xp / max(||Xp||, 1e-12) written with row stride ldz (one slot of the concat output)
+ *   bwd : from dXp (gradient w.r.t. Xp): dP1, dP2 (pre-activation gradients), dN = dA1 + dA2 * X,
+ *         dXd = dA1 + dA2 * N with dAi = dPi Wip^T.  The caller finishes dX = A^T dN + dXd
+ *         (tagrec_spmm_axpy_f32).
+ *   wgrad: dW1p = (N + X)^T dP1, dW2p = (N * X)^T dP2 (deterministic two-stage reduction; workspace of
+ *         tagrec_ngcf_wgrad_workspace(Din, Dout) floats).  db = column sums of dWp (the bias broadcast).
+ * Din, Dout in {16, 32, 64, 128}. */
+int64_t tagrec_ngcf_wgrad_workspace(int Din, int Dout);
+int tagrec_ngcf_dense_fwd_f32(const float* N, const float* X, const float* W1p, const float* W2p,
+                              int64_t n_rows, int Din, int Dout, float* Xp, float* inv_norm, float* Z,
+                              int64_t ldz, void* stream);
+int tagrec_ngcf_dense_bwd_f32(const float* dXp, const float* N, const float* X, const float* W1p,
+                              const float* W2p, int64_t n_rows, int Din, int Dout, float* dN, float* dXd,
+                              float* dP1, float* dP2, void* stream);
+int tagrec_ngcf_wgrad_f32(const float* N, const float* X, const float* dP1, const float* dP2, int64_t n_rows,
+                          int Din, int Dout, float* dW1p, float* dW2p, float* workspace,
+                          int64_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,13 @@ _SIGNATURES = {
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_bpr_bwd_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                            c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tagrec_ngcf_wgrad_workspace": [c_int, c_int],
+    "tagrec_ngcf_dense_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_int64, c_void_p],
+    "tagrec_ngcf_dense_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p],
+    "tagrec_ngcf_wgrad_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                              c_void_p, c_int64, c_void_p],
     "tagrec_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int64,
                         c_void_p],
 }
@@ -59,7 +66,7 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header and library disagree
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_int64 if name.endswith("_workspace") else c_int
     lib.tagrec_last_error.argtypes = []
     lib.tagrec_last_error.restype = c_char_p
     if lib.tagrec_abi_version() != ABI_VERSION:

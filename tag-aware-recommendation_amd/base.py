@@ -1,0 +1,81 @@
+"""Shared plumbing of the table-based models (LightGCN, NGCF): one contiguous [N, D] parameter whose
+row slices are the reference's per-type tables, the `embed.k` state-dict layout, and the cached
+`predict_rating` (/root/reference/model/lightgcn.py:37-47,84-89; model/ngcf.py:39-44,107-112)."""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def xavier_tables(num_list, dim, device):
+    """xavier_uniform_ per table, in order, drawn from torch's CPU generator so a seeded run
+    reproduces the reference's initial values (lightgcn.py:37-47)."""
+    parts = []
+    for n in num_list:
+        t = torch.empty(n, dim)
+        nn.init.xavier_uniform_(t)
+        parts.append(t)
+    return torch.cat(parts, dim=0).to(device)
+
+
+class TableModel(nn.Module):
+    def _init_table(self, data, use_tag, dim, device):
+        if torch.device(device).type != "cuda":
+            raise _lib.TagrecError(f"{type(self).__name__}: tagrec_amd needs a GPU device (no CPU path)")
+        _lib.load()
+        self.num_list = [data.num["user"], data.num["item"]] + ([data.num["tag"]] if use_tag else [])
+        self.table = nn.Parameter(xavier_tables(self.num_list, dim, device))
+        self._offsets = [0]
+        for n in self.num_list:
+            self._offsets.append(self._offsets[-1] + n)
+        self._eval_cache = None
+        self._register_state_dict_hook(_split_table_hook)
+        self._register_load_state_dict_pre_hook(_merge_table_hook, with_module=True)
+
+    @property
+    def embed(self):
+        return [self.table[a:b] for a, b in zip(self._offsets[:-1], self._offsets[1:])]
+
+    def get_ego_embed(self):
+        return self.embed
+
+    get_ego_emb = get_ego_embed          # ngcf.py:92 spells it without the final 'ed'
+
+    def _split(self, out):
+        return tuple(out[a:b] for a, b in zip(self._offsets[:-1], self._offsets[1:]))
+
+    def train(self, mode=True):
+        self._eval_cache = None          # parameters may change once training resumes
+        return super().train(mode)
+
+    def predict_rating(self, users):
+        """sigmoid(U_b I^T).  The reference re-runs forward() for every 512-user batch
+        (lightgcn.py:85).  In eval mode the propagated tables are computed once and reused until
+        `train()` is called again (same values, fewer propagations); in training mode every call
+        propagates, as the reference does."""
+        if self.training or self._eval_cache is None:
+            with torch.no_grad():
+                all_users, all_items = self.forward()[:2]
+            if not self.training:
+                self._eval_cache = (all_users, all_items)
+        else:
+            all_users, all_items = self._eval_cache
+        users = users.to(self.table.device)
+        return torch.sigmoid(torch.matmul(all_users[users], all_items.t()))
+
+
+def _split_table_hook(module, state_dict, prefix, local_metadata):
+    table = state_dict.pop(prefix + "table")
+    for k, (a, b) in enumerate(zip(module._offsets[:-1], module._offsets[1:])):
+        state_dict[f"{prefix}embed.{k}"] = table[a:b]
+    # keep the reference's key order: embed.* first
+    for key in [k for k in state_dict if k.startswith(prefix) and not k.startswith(prefix + "embed.")]:
+        state_dict.move_to_end(key)
+    return state_dict
+
+
+def _merge_table_hook(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    keys = [f"{prefix}embed.{k}" for k in range(len(module.num_list))]
+    module._eval_cache = None
+    if all(k in state_dict for k in keys):
+        state_dict[prefix + "table"] = torch.cat([state_dict.pop(k) for k in keys], dim=0)

@@ -1,0 +1,369 @@
+// K3: the dense half of an NGCF layer on the gfx950 matrix cores (exact-fp32 MFMA 16x16x4).
+//
+// Replaces, per layer k of /root/reference/model/ngcf.py:73-90 (after `nei = split_mm(A, X)`):
+//     S  = LeakyReLU_0.2((nei + X) (W1 + b1));   Bi = LeakyReLU_0.2((nei * X) (W2 + b2))
+//     X' = S + Bi;   Z = F.normalize(X')         (W + b: the 1 x Dout bias is added to the WEIGHT)
+// and the autograd backward of that block.  W' = W + b is formed by the caller (tiny).
+//
+// Layout trick: every product is computed TRANSPOSED (P^T = W'^T A^T) so that the MFMA "column"
+// index (lane & 15) is always the node row and the 4 accumulator registers are 4 consecutive
+// features.  One register layout -- lane (r = lane&15, q = lane>>4) owns features {16 b + 4 q + v} of
+// row r -- then serves as MFMA B-operand of the next product, as the float4 global load/store
+// shape, and as the row-norm reduction shape (xor 16, 32); nothing is transposed through LDS.
+//   forward      P^T  = W'^T . A^T      A-operand W'[k][m]  from LDS (k-major, stride Dout+4)
+//   backward dA  dA^T = W'   . dP^T     A-operand W'[i][k]  from LDS (transposed copy, stride Din+4)
+//   backward dW  dW'  = A^T  . dP       both operands straight from global (rows on the k axis)
+// HBM-bound (about 2 GB per layer and pass at C3); the MFMA work is ~0.2 ms per product at C3.
+#include "common.h"
+
+namespace tagrec {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kNgcfThreads = 256;     // 4 waves, 16 rows each -> 64-row tiles
+constexpr float kSlope = 0.2f;
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : kSlope * x; }
+__device__ __forceinline__ float lrelu_grad(float x) { return x > 0.f ? 1.f : kSlope; }
+
+template <int DIN, int DOUT>
+struct NgcfShape {
+  static constexpr int IB = DIN / 16, MB = DOUT / 16;
+  static constexpr int LDW = DOUT + 4;   // k-major W' rows: lanes run over the Dout index
+  static constexpr int LDT = DIN + 4;    // transposed copy: lanes run over the Din index
+};
+
+// cooperative fill of the LDS copies of W' (row-major [DIN][DOUT] in global memory)
+template <int DIN, int DOUT, bool WITH_T>
+__device__ __forceinline__ void load_weights(const float* __restrict__ W1, const float* __restrict__ W2, float* lds) {
+  using S = NgcfShape<DIN, DOUT>;
+  float* w1 = lds;
+  float* w2 = w1 + DIN * S::LDW;
+  float* t1 = w2 + DIN * S::LDW;
+  float* t2 = t1 + DOUT * S::LDT;
+  for (int e = threadIdx.x; e < DIN * DOUT; e += kNgcfThreads) {
+    const int k = e / DOUT, m = e % DOUT;
+    const float a = W1[e], b = W2[e];
+    w1[k * S::LDW + m] = a;
+    w2[k * S::LDW + m] = b;
+    if constexpr (WITH_T) {
+      t1[m * S::LDT + k] = a;
+      t2[m * S::LDT + k] = b;
+    }
+  }
+  __syncthreads();
+}
+
+// P1^T, P2^T for the wave's 16 rows; a1/a2 are the lane's operand registers (see header comment)
+template <int DIN, int DOUT>
+__device__ __forceinline__ void product_pair(const float* lds, const f32x4 (&a1)[DIN / 16], const f32x4 (&a2)[DIN / 16],
+                                             f32x4 (&p1)[DOUT / 16], f32x4 (&p2)[DOUT / 16], int lane) {
+  using S = NgcfShape<DIN, DOUT>;
+  const float* w1 = lds;
+  const float* w2 = w1 + DIN * S::LDW;
+  const int m = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int mb = 0; mb < S::MB; ++mb) { p1[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; p2[mb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int ib = 0; ib < S::IB; ++ib) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = ib * 16 + q * 4 + v;
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb) {
+        p1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k * S::LDW + mb * 16 + m], a1[ib][v], p1[mb], 0, 0, 0);
+        p2[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[k * S::LDW + mb * 16 + m], a2[ib][v], p2[mb], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int DIN>
+__device__ __forceinline__ void load_inputs(const float* __restrict__ Nn, const float* __restrict__ X, int64_t row,
+                                            bool ok, int q, f32x4 (&nn)[DIN / 16], f32x4 (&x)[DIN / 16]) {
+#pragma unroll
+  for (int ib = 0; ib < DIN / 16; ++ib) {
+    if (ok) {
+      nn[ib] = *reinterpret_cast<const f32x4*>(Nn + row * DIN + ib * 16 + q * 4);
+      x[ib] = *reinterpret_cast<const f32x4*>(X + row * DIN + ib * 16 + q * 4);
+    } else {
+      nn[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      x[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+// ---- forward -----------------------------------------------------------------------------------
+template <int DIN, int DOUT>
+__global__ __launch_bounds__(kNgcfThreads, 2) void ngcf_fwd_kernel(const float* __restrict__ Nn, const float* __restrict__ X,
+                                                                const float* __restrict__ W1, const float* __restrict__ W2,
+                                                                int64_t n_rows, float* __restrict__ Xp,
+                                                                float* __restrict__ inv_norm, float* __restrict__ Z,
+                                                                int64_t ldz) {
+  using S = NgcfShape<DIN, DOUT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  load_weights<DIN, DOUT, false>(W1, W2, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (n_rows + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row = tile * 64 + wave * 16 + r;
+    const bool ok = row < n_rows;
+    f32x4 nn[S::IB], x[S::IB], a1[S::IB], a2[S::IB], p1[S::MB], p2[S::MB];
+    load_inputs<DIN>(Nn, X, row, ok, q, nn, x);
+#pragma unroll
+    for (int ib = 0; ib < S::IB; ++ib) { a1[ib] = nn[ib] + x[ib]; a2[ib] = nn[ib] * x[ib]; }
+    product_pair<DIN, DOUT>(lds, a1, a2, p1, p2, lane);
+    float ss = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < S::MB; ++mb) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float o = lrelu(p1[mb][v]) + lrelu(p2[mb][v]);
+        p1[mb][v] = o;
+        ss = fmaf(o, o, ss);
+      }
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    const float den = fmaxf(sqrtf(ss), 1e-12f);
+    if (ok) {
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb) {
+        *reinterpret_cast<f32x4*>(Xp + row * DOUT + mb * 16 + q * 4) = p1[mb];
+        f32x4 z = p1[mb];
+        z[0] /= den; z[1] /= den; z[2] /= den; z[3] /= den;
+        *reinterpret_cast<f32x4*>(Z + row * ldz + mb * 16 + q * 4) = z;
+      }
+      if (q == 0) inv_norm[row] = 1.0f / den;
+    }
+  }
+}
+
+// ---- backward, activation part: dN, dX_direct and the pre-activation gradients dP1, dP2 ----------
+template <int DIN, int DOUT>
+__global__ __launch_bounds__(kNgcfThreads) void ngcf_bwd_kernel(const float* __restrict__ dXp, const float* __restrict__ Nn,
+                                                                const float* __restrict__ X, const float* __restrict__ W1,
+                                                                const float* __restrict__ W2, int64_t n_rows,
+                                                                float* __restrict__ dNn, float* __restrict__ dXd,
+                                                                float* __restrict__ dP1, float* __restrict__ dP2) {
+  using S = NgcfShape<DIN, DOUT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  load_weights<DIN, DOUT, true>(W1, W2, lds);
+  const float* t1 = lds + 2 * DIN * S::LDW;
+  const float* t2 = t1 + DOUT * S::LDT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (n_rows + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row = tile * 64 + wave * 16 + r;
+    const bool ok = row < n_rows;
+    f32x4 nn[S::IB], x[S::IB], a1[S::IB], a2[S::IB], p1[S::MB], p2[S::MB];
+    load_inputs<DIN>(Nn, X, row, ok, q, nn, x);
+#pragma unroll
+    for (int ib = 0; ib < S::IB; ++ib) { a1[ib] = nn[ib] + x[ib]; a2[ib] = nn[ib] * x[ib]; }
+    product_pair<DIN, DOUT>(lds, a1, a2, p1, p2, lane);      // recompute the pre-activations
+#pragma unroll
+    for (int mb = 0; mb < S::MB; ++mb) {
+      f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok) g = *reinterpret_cast<const f32x4*>(dXp + row * DOUT + mb * 16 + q * 4);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        p1[mb][v] = g[v] * lrelu_grad(p1[mb][v]);
+        p2[mb][v] = g[v] * lrelu_grad(p2[mb][v]);
+      }
+      if (ok) {
+        *reinterpret_cast<f32x4*>(dP1 + row * DOUT + mb * 16 + q * 4) = p1[mb];
+        *reinterpret_cast<f32x4*>(dP2 + row * DOUT + mb * 16 + q * 4) = p2[mb];
+      }
+    }
+    // dA^T = W' . dP^T : contraction over the Dout index, operand = the registers just formed
+#pragma unroll
+    for (int ib = 0; ib < S::IB; ++ib) {
+      f32x4 d1 = f32x4{0.f, 0.f, 0.f, 0.f}, d2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int k = mb * 16 + q * 4 + v;
+          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[k * S::LDT + ib * 16 + r], p1[mb][v], d1, 0, 0, 0);
+          d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(t2[k * S::LDT + ib * 16 + r], p2[mb][v], d2, 0, 0, 0);
+        }
+      }
+      if (ok) {
+        *reinterpret_cast<f32x4*>(dNn + row * DIN + ib * 16 + q * 4) = d1 + d2 * x[ib];
+        *reinterpret_cast<f32x4*>(dXd + row * DIN + ib * 16 + q * 4) = d1 + d2 * nn[ib];
+      }
+    }
+  }
+}
+
+// ---- backward, weight part: dW1' = (N+X)^T dP1, dW2' = (N*X)^T dP2 -------------------------------
+// Each wave owns a contiguous strip of rows and a full set of DIN x DOUT accumulators; partial sums
+// go to a slab [wave][2][DIN*DOUT] that a second kernel folds in wave order (deterministic).
+template <int DIN, int DOUT>
+__global__ __launch_bounds__(kNgcfThreads, 2) void ngcf_wgrad_kernel(const float* __restrict__ Nn, const float* __restrict__ X,
+                                                                  const float* __restrict__ dP1, const float* __restrict__ dP2,
+                                                                  int64_t n_rows, int64_t steps_per_wave,
+                                                                  float* __restrict__ slab) {
+  constexpr int IB = DIN / 16, JB = DOUT / 16;
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, q = lane >> 4;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * (kNgcfThreads / 64) + (threadIdx.x >> 6);
+  f32x4 acc1[IB][JB], acc2[IB][JB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j) { acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int64_t s0 = w * steps_per_wave;
+  for (int64_t s = s0; s < s0 + steps_per_wave; ++s) {
+    const int64_t row = s * 4 + q;
+    if (s * 4 >= n_rows) break;
+    const bool ok = row < n_rows;
+    float a1[IB], a2[IB], b1[JB], b2[JB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const float nv = ok ? Nn[row * DIN + i * 16 + m] : 0.f;
+      const float xv = ok ? X[row * DIN + i * 16 + m] : 0.f;
+      a1[i] = nv + xv;
+      a2[i] = nv * xv;
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      b1[j] = ok ? dP1[row * DOUT + j * 16 + m] : 0.f;
+      b2[j] = ok ? dP2[row * DOUT + j * 16 + m] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], b1[j], acc1[i][j], 0, 0, 0);
+        acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[i], b2[j], acc2[i][j], 0, 0, 0);
+      }
+  }
+  float* o1 = slab + w * 2 * DIN * DOUT;
+  float* o2 = o1 + DIN * DOUT;
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        o1[(i * 16 + q * 4 + v) * DOUT + j * 16 + m] = acc1[i][j][v];
+        o2[(i * 16 + q * 4 + v) * DOUT + j * 16 + m] = acc2[i][j][v];
+      }
+}
+
+__global__ void ngcf_wgrad_reduce_kernel(const float* __restrict__ slab, int n_waves, int elems, float* __restrict__ dW1,
+                                         float* __restrict__ dW2) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * elems) return;
+  float s = 0.f;
+  for (int w = 0; w < n_waves; ++w) s += slab[static_cast<int64_t>(w) * 2 * elems + e];
+  if (e < elems) dW1[e] = s; else dW2[e - elems] = s;
+}
+
+constexpr int kWgradBlocks = 512;   // 2 blocks per CU, 2048 waves
+constexpr int kWgradWaves = kWgradBlocks * (kNgcfThreads / 64);
+
+template <int DIN, int DOUT>
+int launch_fwd(const float* Nn, const float* X, const float* W1, const float* W2, int64_t n, float* Xp, float* inv,
+               float* Z, int64_t ldz, hipStream_t s) {
+  using S = NgcfShape<DIN, DOUT>;
+  const size_t lds = sizeof(float) * 2 * DIN * S::LDW;
+  const int64_t tiles = (n + 63) / 64;
+  const unsigned grid = static_cast<unsigned>(tiles < 1024 ? tiles : 1024);
+  ngcf_fwd_kernel<DIN, DOUT><<<grid, kNgcfThreads, lds, s>>>(Nn, X, W1, W2, n, Xp, inv, Z, ldz);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+template <int DIN, int DOUT>
+int launch_bwd(const float* dXp, const float* Nn, const float* X, const float* W1, const float* W2, int64_t n,
+               float* dNn, float* dXd, float* dP1, float* dP2, hipStream_t s) {
+  using S = NgcfShape<DIN, DOUT>;
+  const size_t lds = sizeof(float) * (2 * DIN * S::LDW + 2 * DOUT * S::LDT);
+  const int64_t tiles = (n + 63) / 64;
+  const unsigned grid = static_cast<unsigned>(tiles < 1024 ? tiles : 1024);
+  auto kern = ngcf_bwd_kernel<DIN, DOUT>;
+  if (lds > 64 * 1024)
+    TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
+  kern<<<grid, kNgcfThreads, lds, s>>>(dXp, Nn, X, W1, W2, n, dNn, dXd, dP1, dP2);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+template <int DIN, int DOUT>
+int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float* dP2, int64_t n, float* dW1, float* dW2,
+                 float* ws, hipStream_t s) {
+  const int64_t steps = (n + 3) / 4;
+  const int64_t per = (steps + kWgradWaves - 1) / kWgradWaves;
+  ngcf_wgrad_kernel<DIN, DOUT><<<kWgradBlocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws);
+  TAGREC_LAUNCH_CHECK();
+  const int elems = DIN * DOUT;
+  ngcf_wgrad_reduce_kernel<<<(2 * elems + 255) / 256, 256, 0, s>>>(ws, kWgradWaves, elems, dW1, dW2);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+#define TAGREC_NGCF_DISPATCH(CALL)                                                          \
+  switch (Din * 1000 + Dout) {                                                              \
+    case 16016: return CALL(16, 16);   case 16032: return CALL(16, 32);                     \
+    case 16064: return CALL(16, 64);   case 16128: return CALL(16, 128);                    \
+    case 32016: return CALL(32, 16);   case 32032: return CALL(32, 32);                     \
+    case 32064: return CALL(32, 64);   case 32128: return CALL(32, 128);                    \
+    case 64016: return CALL(64, 16);   case 64032: return CALL(64, 32);                     \
+    case 64064: return CALL(64, 64);   case 64128: return CALL(64, 128);                    \
+    case 128016: return CALL(128, 16); case 128032: return CALL(128, 32);                   \
+    case 128064: return CALL(128, 64); case 128128: return CALL(128, 128);                  \
+    default: break;                                                                         \
+  }                                                                                         \
+  return fail(TAGREC_E_UNSUPPORTED, "ngcf: layer widths must be 16, 32, 64 or 128 (got " +  \
+                                        std::to_string(Din) + " -> " + std::to_string(Dout) + ")")
+
+}  // namespace tagrec
+
+using namespace tagrec;
+
+extern "C" int64_t tagrec_ngcf_wgrad_workspace(int Din, int Dout) {
+  return static_cast<int64_t>(kWgradWaves) * 2 * Din * Dout;
+}
+
+extern "C" int tagrec_ngcf_dense_fwd_f32(const float* Nn, const float* X, const float* W1p, const float* W2p,
+                                         int64_t n_rows, int Din, int Dout, float* Xp, float* inv_norm, float* Z,
+                                         int64_t ldz, void* stream) {
+  TAGREC_REQUIRE(Nn && X && W1p && W2p && Xp && inv_norm && Z, "ngcf_dense_fwd: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && ldz >= Dout && (ldz % 4) == 0, "ngcf_dense_fwd: bad shape (ldz must be a multiple of 4)");
+  TAGREC_REQUIRE(aligned16(Nn) && aligned16(X) && aligned16(Xp) && aligned16(Z), "ngcf_dense_fwd: rows must be 16-byte aligned");
+  if (n_rows == 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(A, B) launch_fwd<A, B>(Nn, X, W1p, W2p, n_rows, Xp, inv_norm, Z, ldz, s)
+  TAGREC_NGCF_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int tagrec_ngcf_dense_bwd_f32(const float* dXp, const float* Nn, const float* X, const float* W1p,
+                                         const float* W2p, int64_t n_rows, int Din, int Dout, float* dNn, float* dXd,
+                                         float* dP1, float* dP2, void* stream) {
+  TAGREC_REQUIRE(dXp && Nn && X && W1p && W2p && dNn && dXd && dP1 && dP2, "ngcf_dense_bwd: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0, "ngcf_dense_bwd: bad shape");
+  TAGREC_REQUIRE(aligned16(dXp) && aligned16(Nn) && aligned16(X) && aligned16(dNn) && aligned16(dXd) && aligned16(dP1) &&
+                     aligned16(dP2), "ngcf_dense_bwd: rows must be 16-byte aligned");
+  if (n_rows == 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(A, B) launch_bwd<A, B>(dXp, Nn, X, W1p, W2p, n_rows, dNn, dXd, dP1, dP2, s)
+  TAGREC_NGCF_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int tagrec_ngcf_wgrad_f32(const float* Nn, const float* X, const float* dP1, const float* dP2, int64_t n_rows,
+                                     int Din, int Dout, float* dW1p, float* dW2p, float* workspace,
+                                     int64_t workspace_floats, void* stream) {
+  TAGREC_REQUIRE(Nn && X && dP1 && dP2 && dW1p && dW2p && workspace, "ngcf_wgrad: null pointer");
+  TAGREC_REQUIRE(workspace_floats >= tagrec_ngcf_wgrad_workspace(Din, Dout), "ngcf_wgrad: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(A, B) launch_wgrad<A, B>(Nn, X, dP1, dP2, n_rows, dW1p, dW2p, workspace, s)
+  TAGREC_NGCF_DISPATCH(CALL);
+#undef CALL
+}

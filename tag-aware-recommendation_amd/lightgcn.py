@@ -16,19 +16,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, help as H
+from .base import TableModel, xavier_tables  # noqa: F401  (xavier_tables re-exported)
 from .config import CFG as _GLOBAL_CFG
 from .graph import Graph, creat_adj
-
-
-def xavier_tables(num_list, dim, device):
-    """`_init_weight` (lightgcn.py:37-47): xavier_uniform_ per table, in order, drawn from
-    torch's CPU generator so a seeded run reproduces the reference's initial values."""
-    parts = []
-    for n in num_list:
-        t = torch.empty(n, dim)
-        nn.init.xavier_uniform_(t)
-        parts.append(t)
-    return torch.cat(parts, dim=0).to(device)
 
 
 def propagate_forward(graph, x0, n_layer):
@@ -129,23 +119,13 @@ class _PropagateBprLoss(torch.autograd.Function):
         return g0, None, None, None, None, None, None, None
 
 
-class LightGCN(nn.Module):
+class LightGCN(TableModel):
     def __init__(self, data, args=None, config=None, graph=None):
         super().__init__()
         self._config(config if config is not None else _GLOBAL_CFG)
-        if self.device.type != "cuda":
-            raise _lib.TagrecError("LightGCN: tagrec_amd needs a GPU device (no CPU path)")
-        _lib.load()
-        self.num_list = [data.num["user"], data.num["item"]] + ([data.num["tag"]] if self.use_tag else [])
+        self._init_table(data, self.use_tag, self.dim_latent, self.device)
         self.norm_adj = graph if graph is not None else creat_adj(data, self.use_tag, self.norm_type,
                                                                   self.split_adj_k, self.device)
-        self.table = nn.Parameter(xavier_tables(self.num_list, self.dim_latent, self.device))
-        self._offsets = [0]
-        for n in self.num_list:
-            self._offsets.append(self._offsets[-1] + n)
-        self._eval_cache = None
-        self._register_state_dict_hook(_split_table_hook)
-        self._register_load_state_dict_pre_hook(_merge_table_hook, with_module=True)
 
     def _config(self, config):
         self.dim_latent = config["dim_latent"]
@@ -158,14 +138,6 @@ class LightGCN(nn.Module):
         self.use_tag = config["use_tag"]
         self.message_drop_list = config["message_drop_list"]
         self.node_drop = config["node_drop"]
-
-    # ---- reference attribute names -------------------------------------------------------------
-    @property
-    def embed(self):
-        return [self.table[a:b] for a, b in zip(self._offsets[:-1], self._offsets[1:])]
-
-    def get_ego_embed(self):
-        return self.embed
 
     def _fused_ok(self):
         drop = self.training and any(p > 0 for p in self.message_drop_list[:self.num_layer])
@@ -188,8 +160,7 @@ class LightGCN(nn.Module):
         return torch.mean(torch.stack(layers, dim=1), dim=1)
 
     def forward(self):
-        out = self._propagate()
-        return tuple(out[a:b] for a, b in zip(self._offsets[:-1], self._offsets[1:]))
+        return self._split(self._propagate())
 
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
@@ -202,35 +173,3 @@ class LightGCN(nn.Module):
         ego = self.embed
         loss, reg_loss = H.triplet_loss(all_users, all_items, ego[0], ego[1], batch_data, self.loss_func)
         return loss, self.reg * reg_loss
-
-    def train(self, mode=True):
-        self._eval_cache = None          # parameters may change once training resumes
-        return super().train(mode)
-
-    def predict_rating(self, users):
-        """The reference re-runs forward() for every 512-user batch (lightgcn.py:85).  In eval mode the
-        propagated tables are computed once and reused until `train()` is called again (same values,
-        fewer propagations); in training mode every call propagates, as the reference does."""
-        if self.training or self._eval_cache is None:
-            with torch.no_grad():
-                all_users, all_items = self.forward()[:2]
-            if not self.training:
-                self._eval_cache = (all_users, all_items)
-        else:
-            all_users, all_items = self._eval_cache
-        users = users.to(self.device)
-        return torch.sigmoid(torch.matmul(all_users[users], all_items.t()))
-
-
-def _split_table_hook(module, state_dict, prefix, local_metadata):
-    table = state_dict.pop(prefix + "table")
-    for k, (a, b) in enumerate(zip(module._offsets[:-1], module._offsets[1:])):
-        state_dict[f"{prefix}embed.{k}"] = table[a:b]
-    return state_dict
-
-
-def _merge_table_hook(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
-    keys = [f"{prefix}embed.{k}" for k in range(len(module.num_list))]
-    module._eval_cache = None
-    if all(k in state_dict for k in keys):
-        state_dict[prefix + "table"] = torch.cat([state_dict.pop(k) for k in keys], dim=0)

@@ -1,0 +1,215 @@
+"""NGCF behind the reference's model surface (/root/reference/model/ngcf.py).
+
+    NGCF(data)               embed.* tables + mat.W1_k / b1_k / W2_k / b2_k                      (:9-60)
+    .forward()               -> tuple of [n_type, sum(dims)] concatenated layer outputs          (:62-90)
+    .loss(batch[B,3])        -> (mul_loss, reg * l2reg_loss on the PROPAGATED rows)              (:95-105)
+    .predict_rating(users)                                                                       (:107-112)
+
+Per layer: one HIP SpMM (N = A X, A = D^-1 A + I is NOT symmetric, so backward multiplies by the
+transposed CSR), one MFMA kernel for both dense transforms + LeakyReLU + add + L2-normalise that
+writes its slot of the concatenated output in place, and a hand-derived backward
+(normalise-bwd -> activation/dA MFMA kernel -> weight-gradient MFMA kernel -> transposed SpMM).
+The reference's `W + b` quirk (bias broadcast-added to the WEIGHT, :78,:82) is kept: W' = W + b is
+formed on the device, dW = dW', db = column sums of dW'.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, help as H
+from .base import TableModel
+from .config import CFG as _GLOBAL_CFG
+from .graph import Graph, creat_adj
+
+
+def dense_forward(nei, x, w1p, w2p, xp, inv, z_slot, ldz):
+    n, din = x.shape
+    _lib.check(_lib.load().tagrec_ngcf_dense_fwd_f32(_lib.ptr(nei), _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n, din,
+                                                     w1p.shape[1], _lib.ptr(xp), _lib.ptr(inv), _lib.ptr(z_slot), ldz,
+                                                     _lib.stream_ptr()), "ngcf_dense_fwd")
+
+
+def dense_backward(dxp, nei, x, w1p, w2p):
+    n, din = x.shape
+    dout = w1p.shape[1]
+    d_nei, d_xd = torch.empty_like(x), torch.empty_like(x)
+    dp1, dp2 = torch.empty(n, dout, device=x.device), torch.empty(n, dout, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.tagrec_ngcf_dense_bwd_f32(_lib.ptr(dxp), _lib.ptr(nei), _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n,
+                                             din, dout, _lib.ptr(d_nei), _lib.ptr(d_xd), _lib.ptr(dp1), _lib.ptr(dp2),
+                                             _lib.stream_ptr()), "ngcf_dense_bwd")
+    ws_n = lib.tagrec_ngcf_wgrad_workspace(din, dout)
+    ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+    dw1, dw2 = torch.empty_like(w1p), torch.empty_like(w2p)
+    _lib.check(lib.tagrec_ngcf_wgrad_f32(_lib.ptr(nei), _lib.ptr(x), _lib.ptr(dp1), _lib.ptr(dp2), n, din, dout,
+                                         _lib.ptr(dw1), _lib.ptr(dw2), _lib.ptr(ws), ws_n, _lib.stream_ptr()),
+               "ngcf_wgrad")
+    return d_nei, d_xd, dw1, dw2
+
+
+def propagate_forward(graph, x0, wps, dims):
+    """x0 [N, dims[0]] -> out [N, sum(dims)] = cat(x0, z1..zL) and the per-layer state for backward."""
+    n = x0.shape[0]
+    dtot = sum(dims)
+    out = torch.empty(n, dtot, dtype=torch.float32, device=x0.device)
+    out[:, :dims[0]] = x0
+    saved, x, off = [], x0, dims[0]
+    for k, (w1p, w2p) in enumerate(wps):
+        nei = graph.spmm(x)
+        xp = torch.empty(n, dims[k + 1], dtype=torch.float32, device=x0.device)
+        inv = torch.empty(n, dtype=torch.float32, device=x0.device)
+        dense_forward(nei, x, w1p, w2p, xp, inv, out[:, off:], dtot)
+        saved.append((x, nei, xp, inv, w1p, w2p))
+        x, off = xp, off + dims[k + 1]
+    return out, saved
+
+
+def propagate_backward(graph_t, d_out, saved, dims):
+    """d_out [N, sum(dims)] -> (d_x0, [(dW1', dW2')] per layer)."""
+    n, dtot = d_out.shape
+    lib = _lib.load()
+    offs = [0]
+    for d in dims:
+        offs.append(offs[-1] + d)
+    dws = [None] * len(saved)
+    dx_next = None
+    for k in range(len(saved) - 1, -1, -1):
+        x, nei, xp, inv, w1p, w2p = saved[k]
+        dxp = dx_next if dx_next is not None else torch.empty_like(xp)
+        _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(xp), _lib.ptr(inv), _lib.ptr(d_out[:, offs[k + 1]:]), dtot, 1.0,
+                                              _lib.ptr(dxp), 1 if dx_next is not None else 0, n, dims[k + 1],
+                                              _lib.stream_ptr()), "rownorm_bwd")
+        d_nei, d_xd, dw1, dw2 = dense_backward(dxp, nei, x, w1p, w2p)
+        dws[k] = (dw1, dw2)
+        dx = torch.empty_like(x)
+        graph_t.spmm_axpy(d_nei, d_xd, 1.0, dx)
+        dx_next = dx
+    d0 = d_out[:, :dims[0]]
+    return (dx_next + d0) if dx_next is not None else d0.contiguous(), dws
+
+
+def _mat_grads(dws):
+    out = []
+    for dw1, dw2 in dws:                  # order W1_k, b1_k, W2_k, b2_k (the ParameterDict's order)
+        out += [dw1, dw1.sum(0, keepdim=True), dw2, dw2.sum(0, keepdim=True)]
+    return out
+
+
+def _wps(mats):
+    return [(mats[4 * k] + mats[4 * k + 1], mats[4 * k + 2] + mats[4 * k + 3]) for k in range(len(mats) // 4)]
+
+
+class _Propagate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, dims, table, *mats):
+        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims)
+        ctx.graph, ctx.dims, ctx.saved = graph, dims, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d0, dws = propagate_backward(ctx.graph.transpose(), d_out.contiguous(), ctx.saved, ctx.dims)
+        ctx.saved = None
+        return (None, None, d0, *_mat_grads(dws))
+
+
+class _PropagateBprLoss(torch.autograd.Function):
+    """(table, mats) -> [mul_loss, l2reg_loss(propagated rows)] in one autograd node."""
+
+    @staticmethod
+    def forward(ctx, graph, dims, n_user, n_item, trip, loss_kind, table, *mats):
+        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims)
+        B, dtot = trip.shape[0], out.shape[1]
+        coef = torch.empty(B, dtype=torch.float32, device=out.device)
+        partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=out.device)
+        res = torch.empty(2, dtype=torch.float32, device=out.device)
+        U, I = out[:n_user], out[n_user:n_user + n_item]
+        _lib.check(_lib.load().tagrec_bpr_fwd_f32(_lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(U), _lib.ptr(I), dtot,
+                                                  dtot, _lib.ptr(trip), B, loss_kind, _lib.ptr(coef),
+                                                  _lib.ptr(partials), _lib.ptr(res), _lib.stream_ptr()), "bpr_fwd")
+        ctx.graph, ctx.dims, ctx.saved = graph, dims, saved
+        ctx.out, ctx.trip, ctx.coef, ctx.nu, ctx.ni = out, trip, coef, n_user, n_item
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        out, trip, nu, ni = ctx.out, ctx.trip, ctx.nu, ctx.ni
+        dtot = out.shape[1]
+        d_out = torch.zeros_like(out)
+        U, I = out[:nu], out[nu:nu + ni]
+        dU, dI = d_out[:nu], d_out[nu:nu + ni]
+        _lib.check(_lib.load().tagrec_bpr_bwd_f32(_lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(U), _lib.ptr(I), dtot,
+                                                  dtot, _lib.ptr(trip), trip.shape[0], _lib.ptr(ctx.coef),
+                                                  _lib.ptr(g.contiguous()), 1.0, _lib.ptr(dU), _lib.ptr(dI),
+                                                  _lib.ptr(dU), _lib.ptr(dI), _lib.stream_ptr()), "bpr_bwd")
+        d0, dws = propagate_backward(ctx.graph.transpose(), d_out, ctx.saved, ctx.dims)
+        ctx.saved = ctx.out = None
+        return (None, None, None, None, None, None, d0, *_mat_grads(dws))
+
+
+class NGCF(TableModel):
+    def __init__(self, data, args=None, config=None, graph=None):
+        super().__init__()
+        self._config(config if config is not None else _GLOBAL_CFG)
+        self._init_table(data, self.use_tag, self.dim_latent, self.device)
+        # matrices, in the reference's registration order so a seeded init matches (ngcf.py:45-60)
+        self.mat = nn.ParameterDict()
+        for k in range(self.num_layer):
+            names = [f"W1_{k}", f"b1_{k}"] + ([f"W2_{k}", f"b2_{k}"] if self.agg_type == "bi_agg" else [])
+            for name in names:
+                shape = (self.dim_layer_list[k] if name[0] == "W" else 1, self.dim_layer_list[k + 1])
+                t = torch.empty(*shape)
+                nn.init.xavier_uniform_(t)
+                self.mat[name] = nn.Parameter(t.to(self.device))
+        self.norm_adj = graph if graph is not None else creat_adj(data, self.use_tag, self.norm_type,
+                                                                  self.split_adj_k, self.device)
+
+    def _config(self, config):
+        self.dim_latent = config["dim_latent"]
+        self.num_layer = len(config["dim_layer_list"])
+        self.dim_layer_list = [self.dim_latent] + list(config["dim_layer_list"])
+        self.agg_type = config["agg_type"]
+        self.device = torch.device(config["device"])
+        self.message_drop_list = config["message_drop_list"]
+        self.norm_type = config["norm_type"]
+        self.split_adj_k = config["split_adj_k"]
+        self.reg = config["reg"]
+        self.loss_func = config["mul_loss_func"]
+        self.use_tag = config["use_tag"]
+
+    def _mats(self):
+        return [self.mat[f"{n}_{k}"] for k in range(self.num_layer) for n in ("W1", "b1", "W2", "b2")]
+
+    def _fused_ok(self):
+        drop = self.training and any(p > 0 for p in self.message_drop_list[:self.num_layer])
+        dims_ok = all(d in (16, 32, 64, 128) for d in self.dim_layer_list)
+        return isinstance(self.norm_adj, Graph) and not drop and dims_ok
+
+    def _propagate(self):
+        if self.agg_type != "bi_agg":
+            raise NotImplementedError                         # ngcf.py:65-68
+        if self._fused_ok():
+            return _Propagate.apply(self.norm_adj, tuple(self.dim_layer_list), self.table, *self._mats())
+        # operator-by-operator path (row folds, message dropout, odd widths): ngcf.py:73-90 as written
+        x = self.table
+        outs = [x]
+        for k in range(self.num_layer):
+            nei = H.split_mm(self.norm_adj, x)
+            s = torch.nn.functional.leaky_relu(torch.matmul(nei + x, self.mat[f"W1_{k}"] + self.mat[f"b1_{k}"]), 0.2)
+            b = torch.nn.functional.leaky_relu(torch.matmul(nei * x, self.mat[f"W2_{k}"] + self.mat[f"b2_{k}"]), 0.2)
+            x = torch.nn.functional.dropout(s + b, p=self.message_drop_list[k], training=self.training)
+            outs.append(H.normalize_rows(x))
+        return torch.cat(outs, dim=1)
+
+    def forward(self):
+        return self._split(self._propagate())
+
+    def loss(self, batch_data):
+        batch_data = batch_data.to(self.device, torch.int64).contiguous()
+        nu, ni = self.num_list[0], self.num_list[1]
+        if self.agg_type == "bi_agg" and self._fused_ok():
+            res = _PropagateBprLoss.apply(self.norm_adj, tuple(self.dim_layer_list), nu, ni, batch_data,
+                                          H.loss_kind_id(self.loss_func), self.table, *self._mats())
+            return res[0], self.reg * res[1]
+        all_users, all_items = self.forward()[:2]
+        loss, reg_loss = H.triplet_loss(all_users, all_items, all_users, all_items, batch_data, self.loss_func)
+        return loss, self.reg * reg_loss

@@ -89,14 +89,18 @@ def test_device_bpr_producer_properties():
     assert not np.array_equal(a, b)                                                            # re-sampled every epoch
     sizes = [x.shape[0] for x in prod.mini_batch()]
     assert sizes == [hi - lo for lo, hi in odata.mini_batch_bounds(len(tr), 512)]
-    # negatives are uniform over the non-train items: chi-square-ish check on a dense user
+    # negatives are uniform over the non-train items: Pearson chi-square on the busiest user
     u = np.bincount(tr[:, 0]).argmax()
     draws = np.concatenate([np.asarray(T.BPR_training_data(ds, config=cfg, seed=s).all_train_data.cpu())
-                            for s in range(20)])
+                            for s in range(60)])
     neg = draws[draws[:, 0] == u][:, 2]
     free = np.setdiff1d(np.arange(200), tr[tr[:, 0] == u][:, 1])
-    cnt = np.bincount(neg, minlength=200)[free]
-    assert cnt.min() > 0 and cnt.max() < 4 * cnt.mean()
+    cnt = np.bincount(neg, minlength=200)[free].astype(np.float64)
+    assert cnt.sum() == len(neg)
+    exp = cnt.sum() / len(free)
+    chi2 = ((cnt - exp) ** 2 / exp).sum()
+    dof = len(free) - 1
+    assert chi2 < dof + 6 * np.sqrt(2 * dof), (chi2, dof)
 
 
 @pytest.fixture(scope="module")
