@@ -123,7 +123,7 @@ int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
  *         (tagrec_spmm_axpy_f32).
  *   wgrad: dW1p = (N + X)^T dP1, dW2p = (N * X)^T dP2 (deterministic two-stage reduction; workspace of
  *         tagrec_ngcf_wgrad_workspace(Din, Dout) floats).  db = column sums of dWp (the bias broadcast).
- * Din, Dout in {16, 32, 64, 128}. */
+ * Din, Dout in {16, 32, 64, 128}, except 128 -> 128 (the LDS copies of W' would not fit): TAGREC_E_UNSUPPORTED. */
 int64_t tagrec_ngcf_wgrad_workspace(int Din, int Dout);
 int tagrec_ngcf_dense_fwd_f32(const float* N, const float* X, const float* W1p, const float* W2p,
                               int64_t n_rows, int Din, int Dout, float* Xp, float* inv_norm, float* Z,

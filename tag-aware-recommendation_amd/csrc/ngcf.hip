@@ -254,13 +254,22 @@ __global__ __launch_bounds__(kNgcfThreads, 2) void ngcf_wgrad_kernel(const float
       }
 }
 
-__global__ void ngcf_wgrad_reduce_kernel(const float* __restrict__ slab, int n_waves, int elems, float* __restrict__ dW1,
-                                         float* __restrict__ dW2) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * elems) return;
+// fold the per-wave partials in wave order: 4 threads per element take every 4th wave, then a fixed-order
+// combine -> deterministic and 4x the memory parallelism of one thread per element
+__global__ __launch_bounds__(256) void ngcf_wgrad_reduce_kernel(const float* __restrict__ slab, int n_waves, int elems,
+                                                                 float* __restrict__ dW1, float* __restrict__ dW2) {
+  __shared__ float sh[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
   float s = 0.f;
-  for (int w = 0; w < n_waves; ++w) s += slab[static_cast<int64_t>(w) * 2 * elems + e];
-  if (e < elems) dW1[e] = s; else dW2[e - elems] = s;
+  if (e < 2 * elems)
+    for (int w = part; w < n_waves; w += 4) s += slab[static_cast<int64_t>(w) * 2 * elems + e];
+  sh[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && e < 2 * elems) {
+    const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (e < elems) dW1[e] = t; else dW2[e - elems] = t;
+  }
 }
 
 constexpr int kWgradBlocks = 512;   // 2 blocks per CU, 2048 waves
@@ -302,7 +311,7 @@ int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float*
   ngcf_wgrad_kernel<DIN, DOUT><<<kWgradBlocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws);
   TAGREC_LAUNCH_CHECK();
   const int elems = DIN * DOUT;
-  ngcf_wgrad_reduce_kernel<<<(2 * elems + 255) / 256, 256, 0, s>>>(ws, kWgradWaves, elems, dW1, dW2);
+  ngcf_wgrad_reduce_kernel<<<(2 * elems + 63) / 64, 256, 0, s>>>(ws, kWgradWaves, elems, dW1, dW2);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
@@ -316,10 +325,10 @@ int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float*
     case 64016: return CALL(64, 16);   case 64032: return CALL(64, 32);                     \
     case 64064: return CALL(64, 64);   case 64128: return CALL(64, 128);                    \
     case 128016: return CALL(128, 16); case 128032: return CALL(128, 32);                   \
-    case 128064: return CALL(128, 64); case 128128: return CALL(128, 128);                  \
+    case 128064: return CALL(128, 64);                                                      \
     default: break;                                                                         \
   }                                                                                         \
-  return fail(TAGREC_E_UNSUPPORTED, "ngcf: layer widths must be 16, 32, 64 or 128 (got " +  \
+  return fail(TAGREC_E_UNSUPPORTED, "ngcf: layer widths must be 16, 32, 64 or 128 and not 128 -> 128 (got " +  \
                                         std::to_string(Din) + " -> " + std::to_string(Dout) + ")")
 
 }  // namespace tagrec

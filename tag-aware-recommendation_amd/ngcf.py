@@ -181,7 +181,8 @@ class NGCF(TableModel):
 
     def _fused_ok(self):
         drop = self.training and any(p > 0 for p in self.message_drop_list[:self.num_layer])
-        dims_ok = all(d in (16, 32, 64, 128) for d in self.dim_layer_list)
+        dl = self.dim_layer_list
+        dims_ok = all(d in (16, 32, 64, 128) for d in dl) and all(a * b < 128 * 128 for a, b in zip(dl[:-1], dl[1:]))
         return isinstance(self.norm_adj, Graph) and not drop and dims_ok
 
     def _propagate(self):

@@ -84,7 +84,7 @@ def test_ngcf_unfused_path_matches_fused(golden):
         _grad_close(m2.mat[k].grad.cpu().numpy(), m.mat[k].grad.cpu().numpy(), k)
 
 
-@pytest.mark.parametrize("din,dout", [(64, 64), (64, 32), (32, 16), (16, 64), (128, 128), (16, 16)])
+@pytest.mark.parametrize("din,dout", [(64, 64), (64, 32), (32, 16), (16, 64), (128, 64), (16, 16), (64, 128)])
 def test_dense_layer_kernels_vs_torch(din, dout):
     """The three MFMA kernels in isolation against torch autograd (fp64 reference), ragged row count."""
     torch.manual_seed(din * 7 + dout)
@@ -110,3 +110,11 @@ def test_dense_layer_kernels_vs_torch(din, dout):
     np.testing.assert_allclose(d_xd.cpu().numpy(), ref[1].grad.float().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(dw1.cpu().numpy(), ref[2].grad.float().numpy(), rtol=1e-4, atol=2e-3)
     np.testing.assert_allclose(dw2.cpu().numpy(), ref[3].grad.float().numpy(), rtol=1e-4, atol=2e-3)
+
+
+def test_unsupported_width_is_reported_not_miscomputed():
+    x = torch.randn(64, 128, device=DEV)
+    w = torch.randn(128, 128, device=DEV)
+    with pytest.raises(T.TagrecError, match="128 -> 128"):
+        NG.dense_forward(x, x, w, w, torch.empty(64, 128, device=DEV), torch.empty(64, device=DEV),
+                         torch.empty(64, 128, device=DEV), 128)
