@@ -1,0 +1,295 @@
+"""TGCN behind the reference's model surface (/root/reference/model/tgcn.py).
+
+    TGCN(data)                 embed.{user,item,tag,weight}, layer.k.{U,q,p,Wf,bf,atten1.*,conv.*}   (:140-192)
+    .forward()                 -> (user, item, tag) each [n, (L+1) D] (concat of normalised layers)     (:204-230)
+    .loss(batch[B,3])          BPR (logsigmoid) + reg on propagated rows                                (:235-249)
+    .transtag_loss(batch[B,4]) margin ranking on ||u + t - i||_2 over EGO rows + transtag_reg * L2      (:251-261)
+    .predict_rating(users)                                                                              (:263-268)
+
+What runs where
+  * neighbour-level attention (`Attention1`, :20-37): the k-neighbour gather / softmax / weighted sum and
+    its backward are the HIP kernels of csrc/tgcn.hip; the projections they consume (P = ev W1[:D] + b,
+    Q = ej W2 computed ONCE per neighbour type and layer instead of once per (node, neighbour), WT = the
+    weight-embedding look-up table through W1[D:]) are plain GEMMs;
+  * type-level attention, bit-/vector-level convolutions and the fusion layer (:78-106) are evaluated in
+    row chunks under activation checkpointing, so the [n, 32 D + 48] convolution output the reference
+    materialises for all nodes never exists for more than one chunk (plain GEMMs + elementwise device ops;
+    a fused MFMA kernel for this block is the next kernel to write);
+  * the static neighbour tables are uploaded once (the reference rebuilds and uploads them for every layer
+    of every forward, :194-202; its shuffle there is dead code).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.checkpoint import checkpoint
+
+from . import _lib, help as H
+from .config import CFG as _GLOBAL_CFG
+
+
+class _NbrAttention(torch.autograd.Function):
+    """(P, Q, WT, v, Ej) + static index tables -> attended neighbour embedding [n, D]."""
+
+    @staticmethod
+    def forward(ctx, P, Q, WT, v, Ej, idx, widx):
+        P, Q, WT, v, Ej = (t.contiguous() for t in (P, Q, WT, v, Ej))
+        n, A = P.shape
+        k, D = idx.shape[1], Ej.shape[1]
+        attn = torch.empty(n, k, dtype=torch.float32, device=P.device)
+        out = torch.empty(n, D, dtype=torch.float32, device=P.device)
+        _lib.check(_lib.load().tagrec_tgcn_attn_fwd_f32(_lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v), _lib.ptr(Ej),
+                                                        _lib.ptr(idx), _lib.ptr(widx), n, k, D, A, _lib.ptr(attn),
+                                                        _lib.ptr(out), _lib.stream_ptr()), "tgcn_attn_fwd")
+        ctx.save_for_backward(P, Q, WT, v, Ej, idx, widx, attn)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        P, Q, WT, v, Ej, idx, widx, attn = ctx.saved_tensors
+        n, A = P.shape
+        k, D, n_wt = idx.shape[1], Ej.shape[1], WT.shape[0]
+        lib = _lib.load()
+        dP = torch.empty_like(P)
+        dQ, dEj = torch.zeros_like(Q), torch.zeros_like(Ej)
+        dWT, dv = torch.empty_like(WT), torch.empty_like(v)
+        ws_n = lib.tagrec_tgcn_attn_workspace(n_wt, A)
+        ws = torch.empty(ws_n, dtype=torch.float32, device=P.device)
+        _lib.check(lib.tagrec_tgcn_attn_bwd_f32(_lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v), _lib.ptr(Ej),
+                                                _lib.ptr(idx), _lib.ptr(widx), _lib.ptr(attn), _lib.ptr(d_out.contiguous()),
+                                                n, k, D, A, n_wt, _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dEj), _lib.ptr(dWT),
+                                                _lib.ptr(dv), _lib.ptr(ws), ws_n, _lib.stream_ptr()), "tgcn_attn_bwd")
+        return dP, dQ, dWT, dv, dEj, None, None
+
+
+def neighbour_attention(P, Q, WT, v, Ej, idx, widx):
+    return _NbrAttention.apply(P, Q, WT, v, Ej, idx, widx)
+
+
+class _Att(nn.Module):
+    """Parameter holder with the reference's names (tgcn.py:11-18)."""
+
+    def __init__(self, in_features, atten_dim, dim_w):
+        super().__init__()
+        self.W_1 = nn.Parameter(torch.empty(in_features + dim_w, atten_dim))
+        self.W_2 = nn.Parameter(torch.empty(in_features, atten_dim))
+        self.b = nn.Parameter(torch.empty(1, atten_dim))
+        self.v = nn.Parameter(torch.empty(1, atten_dim))
+
+
+class _ConvW(nn.Module):
+    def __init__(self, *shape):
+        super().__init__()
+        w = torch.empty(*shape)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))      # the draw nn.Conv2d makes at construction (RNG parity)
+        self.weight = nn.Parameter(w)
+
+
+def _dense_block(st, U, q, p, wb, w1, w2, w3, Wf, bf):
+    """Type-level attention -> bit-/vector-level convolutions -> fusion, for a chunk of rows.
+    st [n, 3, D] = (user-side, item-side, tag-side) vectors of each node (tgcn.py:78-106)."""
+    n, _, D = st.shape
+    s = torch.relu(st @ U + q) @ p.t()                        # [n,3,1]
+    e3 = torch.softmax(s, dim=1) * st                         # scaled, NOT summed
+    # bit level: Conv2d(1, C, (3,1)) == a 3 -> C mix per feature
+    bit = torch.relu(torch.matmul(wb[:, 0, :, 0], e3)).reshape(n, -1)        # [n, C*D], channel-major
+    # vector level: Conv2d(1, V, (j, D)), j = 1..3 == dot products over j stacked rows
+    flat = e3.reshape(n, 3 * D)
+    v1 = torch.relu(torch.einsum("nhd,cd->nch", e3, w1[:, 0, 0, :])).reshape(n, -1)
+    v2 = torch.relu(torch.stack([flat[:, :2 * D] @ w2.reshape(-1, 2 * D).t(),
+                                 flat[:, D:] @ w2.reshape(-1, 2 * D).t()], dim=2)).reshape(n, -1)
+    v3 = torch.relu(flat @ w3.reshape(-1, 3 * D).t())
+    y = torch.cat([bit, v1, v2, v3], dim=1)
+    return torch.relu(y @ Wf + bf)
+
+
+class _Layer(nn.Module):
+    """`BasicLayer` (tgcn.py:40-137): same parameter names and registration order."""
+
+    def __init__(self, in_features, out_features, atten_dim, weight_dim, num_bit_conv, num_vector_conv):
+        super().__init__()
+        self.atten1 = nn.ModuleDict()
+        for name in ("user", "item", "tag"):
+            self.atten1.update({name: _Att(in_features, atten_dim, weight_dim)})
+        self.U = nn.Parameter(torch.empty(in_features, atten_dim))
+        self.q = nn.Parameter(torch.empty(1, atten_dim))
+        self.p = nn.Parameter(torch.empty(1, atten_dim))
+        vec = nn.ModuleDict()
+        for j in range(1, 4):
+            vec.update({f"conv_{j}": _ConvW(num_vector_conv, 1, j, in_features)})
+        self.conv = nn.ModuleDict({"bit_level": _ConvW(num_bit_conv, 1, 3, 1), "vec_level": vec})
+        in_k = num_bit_conv * in_features + num_vector_conv * (3 + 2 + 1)
+        self.Wf = nn.Parameter(torch.empty(in_k, out_features))
+        self.bf = nn.Parameter(torch.empty(1, out_features))
+        self.in_features = in_features
+
+    def dense(self, st, chunk_rows, use_checkpoint):
+        args = (self.U, self.q, self.p, self.conv["bit_level"].weight, self.conv["vec_level"]["conv_1"].weight,
+                self.conv["vec_level"]["conv_2"].weight, self.conv["vec_level"]["conv_3"].weight, self.Wf, self.bf)
+        outs = []
+        for lo in range(0, st.shape[0], chunk_rows):
+            part = st[lo:lo + chunk_rows]
+            if use_checkpoint and torch.is_grad_enabled():
+                outs.append(checkpoint(_dense_block, part, *args, use_reentrant=False))
+            else:
+                outs.append(_dense_block(part, *args))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    def forward(self, eu, ei, et, ewp, nbr, chunk_rows, use_checkpoint):
+        D = self.in_features
+        emb = {"user": eu, "item": ei, "tag": et}
+        # per neighbour type: Q = e W2 and the weight look-up table, shared by the two relations it serves
+        Q = {t: emb[t] @ self.atten1[t].W_2 for t in emb}
+        WT = {t: ewp @ self.atten1[t].W_1[D:] for t in emb}
+
+        def att(src, nb, pair):
+            a = self.atten1[nb]
+            P = emb[src] @ a.W_1[:D] + a.b
+            return neighbour_attention(P, Q[nb], WT[nb], a.v.reshape(-1), emb[nb], pair[0], pair[1])
+
+        u_i, u_t, i_u, i_t, t_u, t_i = nbr
+        eu_i, eu_t = att("user", "item", u_i), att("user", "tag", u_t)
+        ei_u, ei_t = att("item", "user", i_u), att("item", "tag", i_t)
+        et_u, et_i = att("tag", "user", t_u), att("tag", "item", t_i)
+        outs = []
+        for trip in ((eu, eu_i, eu_t), (ei_u, ei, ei_t), (et_u, et_i, et)):
+            outs.append(self.dense(torch.stack(trip, dim=1), chunk_rows, use_checkpoint))
+        return outs
+
+
+def neighbor_tables(data, neighbor_k, seed=0):
+    """First-`neighbor_k`-column semantics of the reference's tables (data/tgcn_load.py:41-53 +
+    data/utils.py:87-106 + model/tgcn.py:199) without materialising (n, max_deg): per row of each of the
+    six relations (ui, ut, iu, it, tu, ti), k neighbour ids (+1, 0 = no neighbours) drawn WITH replacement
+    when deg < max_deg and without when deg == max_deg, and the matching integer edge weights."""
+    rng = np.random.RandomState(seed)
+
+    def coo(c):
+        return np.asarray(c.row, np.int64), np.asarray(c.col, np.int64), np.asarray(c.data, np.float32), c.shape
+
+    def csr(c, transpose=False):
+        r, cc, v, shape = coo(c)
+        if transpose:
+            r, cc, shape = cc, r, (shape[1], shape[0])
+        key = r * shape[1] + cc
+        ukey, inv = np.unique(key, return_inverse=True)
+        w = np.bincount(inv, weights=v).astype(np.int64)
+        rows, cols = ukey // shape[1], ukey % shape[1]
+        ptr = np.zeros(shape[0] + 1, np.int64)
+        np.cumsum(np.bincount(rows, minlength=shape[0]), out=ptr[1:])
+        return ptr, cols, w
+
+    out = []
+    for blk, tr in ((data.ui_adj, False), (data.ut_adj, False), (data.ui_adj, True),
+                    (data.it_adj, False), (data.ut_adj, True), (data.it_adj, True)):
+        ptr, cols, w = csr(blk, tr)
+        deg = np.diff(ptr)
+        n, max_deg = len(deg), int(deg.max()) if len(deg) else 0
+        ids = np.zeros((n, neighbor_k), np.int32)
+        wts = np.zeros((n, neighbor_k), np.int32)
+        for r in np.flatnonzero(deg > 0):
+            lo, d = ptr[r], deg[r]
+            if d == max_deg and d >= neighbor_k:
+                pick = lo + rng.permutation(d)[:neighbor_k]
+            else:
+                pick = lo + rng.randint(0, d, size=neighbor_k)
+            ids[r], wts[r] = cols[pick] + 1, w[pick]
+        out.append((ids, wts))
+    return out
+
+
+class TGCN(nn.Module):
+    def __init__(self, data, args=None, config=None, neighbors=None):
+        super().__init__()
+        self._config(config if config is not None else _GLOBAL_CFG)
+        if self.device.type != "cuda":
+            raise _lib.TagrecError("TGCN: tagrec_amd needs a GPU device (no CPU path)")
+        _lib.load()
+        self.num_user, self.num_item, self.num_tag = data.num["user"], data.num["item"], data.num["tag"]
+        self.num_weight = data.num["weight"]
+        # parameters: same construction and registration order as tgcn.py:173-192 (RNG parity)
+        self.embed = nn.ParameterDict({
+            "user": nn.Parameter(torch.empty(self.num_user, self.dim_latent)),
+            "item": nn.Parameter(torch.empty(self.num_item, self.dim_latent)),
+            "tag": nn.Parameter(torch.empty(self.num_tag, self.dim_latent)),
+            "weight": nn.Parameter(torch.empty(self.num_weight, self.dim_weight)),
+        })
+        self.layer = nn.ModuleDict()
+        for k in range(self.num_layer):
+            self.layer.update({f"{k}": _Layer(self.dim_layer_list[k], self.dim_layer_list[k + 1], self.dim_atten,
+                                              self.dim_weight, self.num_bit_conv, self.num_vec_conv)})
+        for prm in self.parameters():
+            nn.init.xavier_uniform_(prm)
+        self.to(self.device)
+        # static neighbour tables, uploaded once: the first neighbor_k columns of the reference's tables
+        if neighbors is None:
+            neighbors = data.get_all_neighbor() if hasattr(data, "get_all_neighbor") else \
+                neighbor_tables(data, self.neighbor_k, self.seed)
+        self.nbr = [tuple(torch.as_tensor(np.asarray(t)[:, :self.neighbor_k].astype(np.int32)).contiguous().to(self.device)
+                          for t in pair) for pair in neighbors]
+        self._eval_cache = None
+
+    def _config(self, config):
+        self.dim_latent = config["dim_latent"]
+        self.dim_weight = config["dim_weight"]
+        self.num_layer = len(config["dim_layer_list"])
+        self.dim_layer_list = [self.dim_latent] + list(config["dim_layer_list"])
+        self.dim_atten = config["dim_atten"]
+        self.num_bit_conv = config["num_bit_conv"]
+        self.num_vec_conv = config["num_vec_conv"]
+        self.message_drop_list = config["message_drop_list"]
+        self.device = torch.device(config["device"])
+        self.neighbor_k = config["neighbor_k"]
+        self.reg = config["reg"]
+        self.transtag_reg = config["transtag_reg"]
+        self.loss_func = config["mul_loss_func"]
+        self.margin = config["margin"]
+        self.seed = config.get("seed", 2020)
+        self.chunk_rows = config.get("tgcn_chunk_rows", 65536)
+        self.use_checkpoint = config.get("tgcn_checkpoint", True)
+
+    def train(self, mode=True):
+        self._eval_cache = None
+        return super().train(mode)
+
+    def forward(self):
+        eu, ei, et, ew = self.embed["user"], self.embed["item"], self.embed["tag"], self.embed["weight"]
+        ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])          # index 0 = pad (tgcn.py:21-24)
+        cu, ci, ct = [eu], [ei], [et]
+        for i, layer in enumerate(self.layer.values()):
+            eu, ei, et = layer(eu, ei, et, ewp, self.nbr, self.chunk_rows, self.use_checkpoint)
+            p = self.message_drop_list[i]
+            if self.training and p > 0:
+                eu, ei, et = (torch.nn.functional.dropout(t, p=p, training=True) for t in (eu, ei, et))
+            cu.append(H.normalize_rows(eu))
+            ci.append(H.normalize_rows(ei))
+            ct.append(H.normalize_rows(et))
+        return torch.cat(cu, dim=1), torch.cat(ci, dim=1), torch.cat(ct, dim=1)
+
+    def get_ego_embed(self):
+        return self.embed["user"], self.embed["item"], self.embed["tag"]
+
+    def loss(self, batch_data):
+        batch_data = batch_data.to(self.device, torch.int64).contiguous()
+        all_users, all_items = self.forward()[:2]
+        loss, reg_loss = H.triplet_loss(all_users, all_items, all_users, all_items, batch_data, self.loss_func)
+        return loss, self.reg * reg_loss
+
+    def transtag_loss(self, batch_data):
+        batch_data = batch_data.to(self.device, torch.int64)
+        user, tag, pos_item, neg_item = batch_data.T
+        eu, ei, et = self.get_ego_embed()
+        ue, te, pe, ne = eu[user], et[tag], ei[pos_item], ei[neg_item]
+        loss = H.transtag_loss(ue, te, pe, ne, self.margin)
+        return loss, self.transtag_reg * H.l2reg_loss(ue, te, pe, ne)
+
+    def predict_rating(self, users):
+        if self.training or self._eval_cache is None:
+            with torch.no_grad():
+                all_users, all_items = self.forward()[:2]
+            if not self.training:
+                self._eval_cache = (all_users, all_items)
+        else:
+            all_users, all_items = self._eval_cache
+        return torch.sigmoid(torch.matmul(all_users[users.to(self.device)], all_items.t()))

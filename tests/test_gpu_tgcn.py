@@ -1,0 +1,136 @@
+"""GPU parity of the TGCN path: HIP neighbour-attention kernels (forward + backward) and the whole model
+against the reference's golden vectors (tests/golden/tgcn_toy.npz) and the CPU oracle.
+
+Tolerances: activations rtol 2e-5 / atol 2e-6; losses rtol 1e-5; gradients rtol 5e-3 with an absolute floor of
+2e-6 x max|grad| per tensor (float-atomic scatter order + different association of the W1 split)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tagrec_amd as T
+from tagrec_amd import tgcn as TG
+from oracle import models as om
+from test_gpu_lightgcn import DEV, _ds_from_fixture
+
+
+def _nbr(fx):
+    return [(fx[f"nbr{r}.ids"], fx[f"nbr{r}.wts"]) for r in range(6)]
+
+
+def _model(fx, seed_init=False, **kw):
+    cfg = T.get_config("tgcn", use_tag=True, dim_layer_list=[int(x) for x in fx["layers"]], dim_latent=int(fx["D"]),
+                       reg=float(fx["reg"]), neighbor_k=int(fx["neighbor_k"]), device=DEV, **kw)
+    ds = _ds_from_fixture(fx)
+    ds.num["weight"] = int(fx["n_weight"])
+    if seed_init:
+        torch.manual_seed(2020)
+    m = T.TGCN(ds, config=cfg, neighbors=_nbr(fx))
+    if not seed_init:
+        m.load_state_dict({k[5:]: torch.from_numpy(fx[k]) for k in fx if k.startswith("init.")})
+    return m
+
+
+def _close(got, want, name, rtol=5e-3):
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=2e-6 * max(1e-3, float(np.abs(want).max())), err_msg=name)
+
+
+def test_seeded_init_reproduces_reference(golden):
+    """torch.manual_seed(2020) + construction draws the reference's initial values (incl. the draws
+    nn.Conv2d consumes at construction, and the ParameterDict key order)."""
+    fx = golden("tgcn_toy")
+    m = _model(fx, seed_init=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k[5:] for k in fx if k.startswith("init.")]
+    for k, v in sd.items():
+        np.testing.assert_array_equal(v.cpu().numpy(), fx["init." + k], err_msg=k)
+
+
+def test_tgcn_forward_loss_grads_golden(golden):
+    fx = golden("tgcn_toy")
+    m = _model(fx)
+    m.eval()
+    with torch.no_grad():
+        outs = m.forward()
+    for t, o in enumerate(outs):
+        np.testing.assert_allclose(o.cpu().numpy(), fx[f"out.{t}"], rtol=2e-5, atol=2e-6)
+    m.train()
+    lossx = m.loss(torch.from_numpy(fx["batches"][0]).to(DEV))
+    np.testing.assert_allclose([float(v) for v in lossx], fx["loss_parts"], rtol=1e-5)
+    sum(lossx).backward()
+    for k, p in m.named_parameters():
+        g = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        _close(g, fx["grad." + k], k)
+
+
+def test_tgcn_chunked_checkpointed_dense_equals_unchunked(golden):
+    fx = golden("tgcn_toy")
+    b = torch.from_numpy(fx["batches"][0]).to(DEV)
+    grads = []
+    for kw in ({"tgcn_chunk_rows": 7, "tgcn_checkpoint": True}, {"tgcn_chunk_rows": 10 ** 6, "tgcn_checkpoint": False}):
+        m = _model(fx, **kw)
+        m.train()
+        sum(m.loss(b)).backward()
+        grads.append({k: p.grad.cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+    for k in grads[0]:
+        _close(grads[0][k], grads[1][k], k, rtol=1e-4)
+
+
+def test_transtag_phase_golden(golden):
+    fx = golden("tgcn_toy")
+    m = _model(fx)
+    lossx = m.transtag_loss(torch.from_numpy(fx["tt_batch"]).to(DEV))
+    np.testing.assert_allclose([float(v) for v in lossx], fx["tt_loss_parts"], rtol=1e-5)
+    sum(lossx).backward()
+    for k in ("user", "item", "tag"):
+        _close(m.embed[k].grad.cpu().numpy(), fx[f"tt_grad.embed.{k}"], k, rtol=1e-4)
+
+
+@pytest.mark.parametrize("D,k,A", [(128, 25, 32), (64, 25, 32), (16, 5, 32), (32, 64, 16), (256, 3, 64)])
+def test_attention_kernels_vs_oracle(D, k, A):
+    """`Attention1` through the HIP kernels vs the oracle's direct restatement, C4-shaped rows (D=128, k=25)."""
+    torch.manual_seed(D + k)
+    n, m, nw, dw = 300, 200, 7, 10
+    ev, ej, ew = torch.randn(n, D) * 0.3, torch.randn(m, D) * 0.3, torch.randn(nw, dw) * 0.3
+    prm = {"W_1": torch.randn(D + dw, A) * 0.2, "W_2": torch.randn(D, A) * 0.2, "b": torch.randn(1, A) * 0.1,
+           "v": torch.randn(1, A)}
+    idx = torch.randint(0, m + 1, (n, k))
+    idx[3] = 0                                                  # a node with no neighbours: all pads
+    widx = torch.where(idx > 0, torch.randint(1, nw + 1, (n, k)), torch.zeros(n, k, dtype=torch.long))
+    up = torch.randn(n, D)
+    ref_in = {kk: v.clone().requires_grad_() for kk, v in prm.items()}
+    rv, rj, rw = (t.clone().requires_grad_() for t in (ev, ej, ew))
+    want = om.tgcn_attention1(ref_in, "", rv, rj, rw, idx, widx)
+    (want * up).sum().backward()
+    g = {kk: v.clone().to(DEV).requires_grad_() for kk, v in prm.items()}
+    gv, gj, gw = (t.clone().to(DEV).requires_grad_() for t in (ev, ej, ew))
+    ewp = torch.cat([gw.new_zeros(1, dw), gw])
+    P = gv @ g["W_1"][:D] + g["b"]
+    got = TG.neighbour_attention(P, gj @ g["W_2"], ewp @ g["W_1"][D:], g["v"].reshape(-1), gj,
+                                 idx.to(DEV, torch.int32).contiguous(), widx.to(DEV, torch.int32).contiguous())
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-6)
+    (got * up.to(DEV)).sum().backward()
+    for name, a, b in (("ev", gv, rv), ("ej", gj, rj), ("ew", gw, rw)):
+        _close(a.grad.cpu().numpy(), b.grad.numpy(), name, rtol=2e-3)
+    for kk in prm:
+        _close(g[kk].grad.cpu().numpy(), ref_in[kk].grad.numpy(), kk, rtol=2e-3)
+
+
+def test_neighbor_tables_semantics():
+    ds = T.synth.make_cf_dataset(50, 40, 400, seed=4, n_tag=15, n_assign=300)
+    tabs = TG.neighbor_tables(ds, 6, seed=1)
+    assert len(tabs) == 6
+    ui = {}
+    for u, i in zip(ds.ui_adj.row, ds.ui_adj.col):
+        ui.setdefault(int(u), set()).add(int(i))
+    ids, wts = tabs[0]
+    assert ids.shape == (50, 6) and ids.dtype == np.int32
+    for u in range(50):
+        got = set(ids[u].tolist())
+        if u in ui:
+            assert 0 not in got and {g - 1 for g in got} <= ui[u] and (wts[u] == 1).all()
+        else:
+            assert got == {0}
+    ids_ut, wts_ut = tabs[1]                       # user-tag: integer co-occurrence weights
+    assert wts_ut.max() >= 1 and (wts_ut[ids_ut == 0] == 0).all()
