@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--model", choices=["lightgcn", "ngcf"], default="lightgcn",
-                    help="lightgcn = C2 (headline); ngcf = C3 (same graph, D^-1 A + I, MFMA dense layers)")
+    ap.add_argument("--model", choices=["lightgcn", "ngcf", "tgcn"], default="lightgcn",
+                    help="lightgcn = C2 (headline); ngcf = C3 (same graph, D^-1 A + I, MFMA dense layers); "
+                         "tgcn = C4 (tripartite, 1M/1M/2M nodes, D=128, k=25; use --steps 3 --warmup 1)")
     return ap.parse_args()
 
 
@@ -92,8 +93,90 @@ def cpu_baseline(args, full_nnz):
                       f"scaled by nnz ratio {full_nnz / nnz_s:.1f} to the full graph"}
 
 
+def bench_tgcn(args):
+    """C4: TGCN 3-layer dim 128 on a synthetic tripartite graph (1M users, 1M items, 2M tags, 100M
+    assignments, k=25 neighbours per relation).  A step = one BPR mini-batch of `epoch_training` phase 0."""
+    import tagrec_amd as T
+    from tagrec_amd import tgcn as TG
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sc = args.scale
+    nu, ni, nt, na = int(1e6 * sc), int(1e6 * sc), int(2e6 * sc), int(1e8 * sc)
+    D = 128 if args.dim == 64 else args.dim
+    L, B, k = args.layers, args.batch, 25
+    cfg = T.get_config("tgcn", dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B, neighbor_k=k)
+    t0 = time.perf_counter()
+    ds = T.synth.make_tripartite_device(nu, ni, nt, na, seed=2, device=dev)
+    torch.manual_seed(cfg["seed"])
+    model = T.TGCN(ds, config=cfg)
+    opt = T.Adam(model.parameters(), lr=cfg["lr"])
+    prod = T.BPR_training_data(ds, config=cfg, seed=2020)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    epoch = prod.all_train_data
+
+    def run(batches, loss_fn):
+        for b in batches:
+            lossx = loss_fn(b)
+            opt.zero_grad()
+            sum(lossx).backward()
+            opt.step()
+        return lossx
+
+    model.train()
+    W, K = args.warmup, args.steps
+    batches = [epoch[i * B:(i + 1) * B] for i in range(W + K)]
+    run(batches[:W], model.loss)
+    TG.timing = {}
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    last = run(batches[W:], model.loss)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    ms = {kk: [a.elapsed_time(b) for a, b in v] for kk, v in TG.timing.items()}
+    TG.timing = None
+    # transtag phase, one step, for the record
+    tt = T.TransTag_training_data(ds, config=cfg, seed=1)
+    tb = tt.all_train_data[:cfg["transtag_batch"]]
+    run([tb], model.transtag_loss)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    run([tt.all_train_data[512:1024]], model.transtag_loss)
+    torch.cuda.synchronize()
+    t_tt = time.perf_counter() - t
+    n_pairs = sum(int(p[0].shape[0]) for p in model.nbr)          # (node, relation) pairs per layer
+    A = cfg["dim_atten"]
+    alg = n_pairs / 6 * k * (4 * D + 4 * A + 8) + n_pairs / 6 * (4 * D + 4 * A + 4 * k)   # mean per launch (one relation)
+    fwd = ms.get("attn_fwd", [])
+    roof = None
+    if fwd:
+        m = sum(fwd) / len(fwd)
+        ach = alg / (m * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "tgcn_attn_fwd_kernel<32> (mean over the six relations)", "achieved": ach,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg, "mean_launch_ms": m, "launches_timed": len(fwd),
+                "other_kernels_ms": {kk: sum(v) / len(v) for kk, v in ms.items() if kk != "attn_fwd"}}
+    n_nodes = nu + ni + nt
+    dense_flop = L * 4 * 2 * n_nodes * (32 * D + 48) * D      # fwd + recompute + 2x bwd of the fusion GEMM
+    out = {"metric": f"BPR triplets/sec, TGCN {L}-layer dim{D}, tripartite {nu}/{ni}/{nt} nodes, k={k}",
+           "value": K * B / dt, "unit": "triplets/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"C4 TGCN L={L} D={D} users={nu} items={ni} tags={nt} assignments={int(ds.uit_data.shape[0])} "
+                                  f"k={k} train_batch={B} adam lr=0.01 logsigmoid", "train_batch": B, "parallelism": "single"},
+           "roofline": roof, "cpu_baseline": None,
+           "extra": {"build_s": round(t_build, 1), "last_loss": [float(x) for x in last],
+                     "transtag_step_ms": t_tt * 1e3, "attention_ms_per_step": (sum(fwd) + sum(ms.get("attn_bwd", []))) / K,
+                     "dense_block_tflops_if_all_remaining_time": dense_flop / 1e12 /
+                     max(1e-9, dt / K - (sum(fwd) + sum(ms.get("attn_bwd", []))) / K * 1e-3),
+                     "note": "dense block (type attention, convolutions, fusion GEMM) runs as rocBLAS GEMMs + elementwise "
+                             "device ops under activation checkpointing; the CPU reference cannot materialise this size"}}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.model == "tgcn":
+        return bench_tgcn(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

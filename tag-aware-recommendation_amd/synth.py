@@ -23,6 +23,7 @@ class Dataset:
         self.user_items = {}
         self.edge_index = {}
         self.uit_data = None
+        self.rel = None           # device CSR relations of the tripartite generator
 
 
 def _zipf_weights(n, alpha):
@@ -181,4 +182,61 @@ def make_bipartite_device(n_user, n_item, n_edge, seed, device, item_alpha=0.8, 
     ds.num = {"user": int(n_user), "item": int(n_item)}
     u = torch.div(key, n_item, rounding_mode="floor")
     ds.edge_index = {"train": torch.stack([u, key - u * n_item], dim=1).contiguous()}
+    return ds
+
+
+def make_tripartite_device(n_user, n_item, n_tag, n_assign, seed, device, item_alpha=0.8, tag_alpha=1.0,
+                           user_mu=3.5, user_sigma=0.8, max_weight=16):
+    """C4-style (user, item, tag) assignments generated on the GPU: `n_assign` draws with
+    item popularity Zipf(item_alpha), tag popularity Zipf(tag_alpha), user activity log-normal; every user,
+    item and tag appears at least once.  Duplicate triples are removed (data/utils.py:9-20), repeated
+    (user, tag) / (item, tag) pairs become integer weights clipped to `max_weight` (num['weight']).
+    Returns a `Dataset` with `uit_data` [T,3] and `edge_index['train']` [E,2] (distinct (u,i)) as int64 device
+    tensors and `rel`: the six relations ui, ut, iu, it, tu, ti as device CSR (rowptr, col, int weight)."""
+    import torch
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+
+    def cdf(w):
+        return torch.cumsum(w / w.sum(), 0)
+
+    ci = cdf(torch.arange(1, n_item + 1, device=dev, dtype=torch.float64).pow(-item_alpha))
+    ct = cdf(torch.arange(1, n_tag + 1, device=dev, dtype=torch.float64).pow(-tag_alpha))
+    cu = cdf(torch.exp(user_mu + user_sigma * torch.randn(n_user, device=dev, dtype=torch.float64, generator=gen)))
+    pi = torch.randperm(n_item, device=dev, generator=gen)
+    pt = torch.randperm(n_tag, device=dev, generator=gen)
+
+    def draw(c, n, m):
+        return torch.searchsorted(c, torch.rand(m, device=dev, dtype=torch.float64, generator=gen)).clamp_(max=n - 1)
+
+    m = n_assign
+    u, i, t = draw(cu, n_user, m), pi[draw(ci, n_item, m)], pt[draw(ct, n_tag, m)]
+    # everyone appears at least once
+    k = max(n_user, n_item, n_tag)
+    ar = torch.arange(k, device=dev)
+    u = torch.cat([u, ar % n_user]); i = torch.cat([i, ar % n_item]); t = torch.cat([t, ar % n_tag])
+    key = torch.unique((u * n_item + i) * n_tag + t)
+    t = key % n_tag
+    ui = torch.div(key, n_tag, rounding_mode="floor")
+    u, i = torch.div(ui, n_item, rounding_mode="floor"), ui % n_item
+    ds = Dataset()
+    ds.uit_data = torch.stack([u, i, t], dim=1).contiguous()
+    uik = torch.unique(ui)
+    eu = torch.div(uik, n_item, rounding_mode="floor")
+    ds.edge_index = {"train": torch.stack([eu, uik - eu * n_item], dim=1).contiguous()}
+
+    def rel(a, b, na, nb, unit=False):
+        k2, cnt = torch.unique(a * nb + b, return_counts=True)
+        r = torch.div(k2, nb, rounding_mode="floor")
+        ptr = torch.zeros(na + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(r, minlength=na), 0, out=ptr[1:])
+        w = torch.ones_like(cnt) if unit else cnt.clamp(max=max_weight)
+        return ptr, (k2 - r * nb).to(torch.int32), w.to(torch.int32)
+
+    ds.rel = {"ui": rel(u, i, n_user, n_item, unit=True), "ut": rel(u, t, n_user, n_tag),
+              "iu": rel(i, u, n_item, n_user, unit=True), "it": rel(i, t, n_item, n_tag),
+              "tu": rel(t, u, n_tag, n_user), "ti": rel(t, i, n_tag, n_item)}
+    wmax = max(int(ds.rel[r][2].max()) for r in ("ut", "it"))
+    ds.num = {"user": int(n_user), "item": int(n_item), "tag": int(n_tag), "weight": int(wmax)}
     return ds

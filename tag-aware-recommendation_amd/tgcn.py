@@ -39,9 +39,9 @@ class _NbrAttention(torch.autograd.Function):
         k, D = idx.shape[1], Ej.shape[1]
         attn = torch.empty(n, k, dtype=torch.float32, device=P.device)
         out = torch.empty(n, D, dtype=torch.float32, device=P.device)
-        _lib.check(_lib.load().tagrec_tgcn_attn_fwd_f32(_lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v), _lib.ptr(Ej),
-                                                        _lib.ptr(idx), _lib.ptr(widx), n, k, D, A, _lib.ptr(attn),
-                                                        _lib.ptr(out), _lib.stream_ptr()), "tgcn_attn_fwd")
+        _lib.check(_timed("attn_fwd", _lib.load().tagrec_tgcn_attn_fwd_f32, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT),
+                          _lib.ptr(v), _lib.ptr(Ej), _lib.ptr(idx), _lib.ptr(widx), n, k, D, A, _lib.ptr(attn),
+                          _lib.ptr(out), _lib.stream_ptr()), "tgcn_attn_fwd")
         ctx.save_for_backward(P, Q, WT, v, Ej, idx, widx, attn)
         return out
 
@@ -56,10 +56,10 @@ class _NbrAttention(torch.autograd.Function):
         dWT, dv = torch.empty_like(WT), torch.empty_like(v)
         ws_n = lib.tagrec_tgcn_attn_workspace(n_wt, A)
         ws = torch.empty(ws_n, dtype=torch.float32, device=P.device)
-        _lib.check(lib.tagrec_tgcn_attn_bwd_f32(_lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v), _lib.ptr(Ej),
-                                                _lib.ptr(idx), _lib.ptr(widx), _lib.ptr(attn), _lib.ptr(d_out.contiguous()),
-                                                n, k, D, A, n_wt, _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dEj), _lib.ptr(dWT),
-                                                _lib.ptr(dv), _lib.ptr(ws), ws_n, _lib.stream_ptr()), "tgcn_attn_bwd")
+        _lib.check(_timed("attn_bwd", lib.tagrec_tgcn_attn_bwd_f32, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v),
+                          _lib.ptr(Ej), _lib.ptr(idx), _lib.ptr(widx), _lib.ptr(attn), _lib.ptr(d_out.contiguous()),
+                          n, k, D, A, n_wt, _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dEj), _lib.ptr(dWT),
+                          _lib.ptr(dv), _lib.ptr(ws), ws_n, _lib.stream_ptr()), "tgcn_attn_bwd")
         return dP, dQ, dWT, dv, dEj, None, None
 
 
@@ -199,6 +199,48 @@ def neighbor_tables(data, neighbor_k, seed=0):
     return out
 
 
+def neighbor_tables_device(rel, neighbor_k, seed=0):
+    """Same first-k semantics as `neighbor_tables`, on the GPU, from device CSR relations
+    (`synth.make_tripartite_device(...).rel`): k draws with replacement per row; rows whose degree equals
+    the relation's maximum get k distinct neighbours (a prefix of a random permutation)."""
+    out = []
+    for name in ("ui", "ut", "iu", "it", "tu", "ti"):
+        ptr, col, w = rel[name]
+        dev = ptr.device
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed + len(out))
+        deg = ptr[1:] - ptr[:-1]
+        n = deg.numel()
+        r = torch.rand(n, neighbor_k, device=dev, generator=gen)
+        pos = ptr[:-1, None] + (r * deg[:, None]).long().clamp_(max=int(deg.max()) - 1).clamp_(min=0)
+        pos = torch.minimum(pos, (ptr[1:, None] - 1).clamp_(min=0))
+        ids = (col[pos.clamp_(max=max(col.numel() - 1, 0))].long() + 1)
+        wts = w[pos].long()
+        has = (deg > 0)[:, None]
+        ids, wts = ids * has, wts * has
+        full = torch.nonzero((deg == deg.max()) & (deg >= neighbor_k)).flatten()
+        for row in full.tolist():                     # the max-degree rows: sampling without replacement
+            lo, d = int(ptr[row]), int(deg[row])
+            pick = lo + torch.randperm(d, device=dev, generator=gen)[:neighbor_k]
+            ids[row], wts[row] = col[pick].long() + 1, w[pick].long()
+        out.append((ids.to(torch.int32).contiguous(), wts.to(torch.int32).contiguous()))
+    return out
+
+
+timing = None     # set to {} to record (start, end) events around the attention kernels (bench.py)
+
+
+def _timed(name, fn, *args):
+    if timing is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    timing.setdefault(name, []).append((e0, e1))
+    return rc
+
+
 class TGCN(nn.Module):
     def __init__(self, data, args=None, config=None, neighbors=None):
         super().__init__()
@@ -224,10 +266,17 @@ class TGCN(nn.Module):
         self.to(self.device)
         # static neighbour tables, uploaded once: the first neighbor_k columns of the reference's tables
         if neighbors is None:
-            neighbors = data.get_all_neighbor() if hasattr(data, "get_all_neighbor") else \
-                neighbor_tables(data, self.neighbor_k, self.seed)
-        self.nbr = [tuple(torch.as_tensor(np.asarray(t)[:, :self.neighbor_k].astype(np.int32)).contiguous().to(self.device)
-                          for t in pair) for pair in neighbors]
+            if hasattr(data, "get_all_neighbor"):
+                neighbors = data.get_all_neighbor()
+            elif getattr(data, "rel", None) is not None:
+                neighbors = neighbor_tables_device(data.rel, self.neighbor_k, self.seed)
+            else:
+                neighbors = neighbor_tables(data, self.neighbor_k, self.seed)
+        def up(t):
+            if isinstance(t, torch.Tensor):
+                return t[:, :self.neighbor_k].to(self.device, torch.int32).contiguous()
+            return torch.as_tensor(np.asarray(t)[:, :self.neighbor_k].astype(np.int32)).contiguous().to(self.device)
+        self.nbr = [tuple(up(t) for t in pair) for pair in neighbors]
         self._eval_cache = None
 
     def _config(self, config):

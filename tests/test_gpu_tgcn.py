@@ -32,8 +32,12 @@ def _model(fx, seed_init=False, **kw):
     return m
 
 
-def _close(got, want, name, rtol=5e-3):
-    np.testing.assert_allclose(got, want, rtol=rtol, atol=2e-6 * max(1e-3, float(np.abs(want).max())), err_msg=name)
+def _close(got, want, name, rtol=5e-3, scale=None):
+    """atol is set from `scale` (the largest gradient entry of the whole model when given): tensors whose
+    gradient is a sum that cancels to ~1e-7 (e.g. the last layer's bias, whose gradient the L2-normalise
+    backward projects out) carry absolute errors of the size of the terms, not of the sum."""
+    scale = float(np.abs(want).max()) if scale is None else scale
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=2e-6 * max(1e-3, scale), err_msg=name)
 
 
 def test_seeded_init_reproduces_reference(golden):
@@ -59,9 +63,10 @@ def test_tgcn_forward_loss_grads_golden(golden):
     lossx = m.loss(torch.from_numpy(fx["batches"][0]).to(DEV))
     np.testing.assert_allclose([float(v) for v in lossx], fx["loss_parts"], rtol=1e-5)
     sum(lossx).backward()
+    scale = max(float(np.abs(fx["grad." + k]).max()) for k, _ in m.named_parameters())
     for k, p in m.named_parameters():
         g = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
-        _close(g, fx["grad." + k], k)
+        _close(g, fx["grad." + k], k, scale=scale)
 
 
 def test_tgcn_chunked_checkpointed_dense_equals_unchunked(golden):
@@ -73,8 +78,9 @@ def test_tgcn_chunked_checkpointed_dense_equals_unchunked(golden):
         m.train()
         sum(m.loss(b)).backward()
         grads.append({k: p.grad.cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+    scale = max(float(np.abs(v).max()) for v in grads[1].values())
     for k in grads[0]:
-        _close(grads[0][k], grads[1][k], k, rtol=1e-4)
+        _close(grads[0][k], grads[1][k], k, rtol=1e-4, scale=scale)
 
 
 def test_transtag_phase_golden(golden):
