@@ -45,7 +45,7 @@ def import_reference():
                 tr_utils=tr_utils, basic_test=basic_test, basic_train=basic_train)
 
 
-def main():
+def main(only=None):
     import scipy.sparse as sp
     import torch
     sys.path.insert(0, ROOT)
@@ -85,6 +85,33 @@ def main():
 
     toy = synth.make_cf_dataset(40, 30, 300, seed=1, n_tag=12, n_assign=200)
     med = synth.make_cf_dataset(200, 300, 5000, seed=2)
+
+    # ------------------------------------------------------------------ loaders (N3): reference TGCN_load on toy files
+    if only in (None, "loader"):
+        import tempfile
+        import data as ref_data
+        with tempfile.TemporaryDirectory() as tmp:
+            tagrec_amd.data.write_dataset(toy, tmp, "toyset")
+            # a repeated user line and a repeated item exercise the merge / de-dup rules of data/utils.py:23-46
+            with open(os.path.join(tmp, "toyset", "train.txt"), "a") as f:
+                f.write("3 1 1 2\n")
+            CFG.update(data_root=tmp, dataset="toyset", has_val=False, cpu_core=1)
+            ld = ref_data.TGCN_load(types.SimpleNamespace(pool=None))
+            fx = {"files." + n: np.frombuffer(open(os.path.join(tmp, "toyset", n), "rb").read(), dtype=np.uint8)
+                  for n in ("train.txt", "test.txt", "user_item_tag.txt")}
+            fx.update({"num." + k: int(v) for k, v in ld.num.items()})
+            for split in ("train", "test"):
+                e = np.asarray(ld.edge_index[split])
+                fx["edges." + split] = e[np.lexsort((e[:, 1], e[:, 0]))]
+            for nm in ("ui_adj", "ut_adj", "it_adj"):
+                m = getattr(ld, nm).tocsr().tocoo()          # duplicates summed, canonical order
+                fx[nm + ".row"], fx[nm + ".col"], fx[nm + ".data"] = m.row, m.col, m.data
+                fx[nm + ".shape"] = np.array(m.shape)
+            fx["uit_data"] = np.asarray(ld.uit_data)
+            np.savez_compressed(os.path.join(OUT, "loader_toy.npz"), **fx)
+            print("wrote loader_toy", ld.num)
+        if only == "loader":
+            return
 
     # ------------------------------------------------------------------ adjacency (A1-A3)
     fx = blocks(toy)
@@ -283,4 +310,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)      # optional: name of a single case ("loader")

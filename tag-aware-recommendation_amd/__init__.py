@@ -14,7 +14,7 @@ Reference name                      here
   utility.word.CFG                    tagrec_amd.CFG (get_config(model, **kw))
 """
 from . import synth  # noqa: F401
-from . import _lib, config, graph, help  # noqa: F401
+from . import _lib, config, data, graph, help  # noqa: F401
 from ._lib import TagrecError  # noqa: F401
 from .config import CFG, get_config, init_seed  # noqa: F401
 from .evaluate import Basic_test  # noqa: F401

@@ -89,3 +89,43 @@ def test_config_defaults_match_reference():
     assert (t["neighbor_k"], t["dim_atten"], t["num_bit_conv"], t["num_vec_conv"], t["margin"]) == (25, 32, 32, 8, 1)
     with pytest.raises(KeyError):
         T.get_config("kgat")
+
+
+def test_text_loader_matches_reference_loader(golden, tmp_path):
+    """tagrec_amd.data.TGCN_load on the same train/test/user_item_tag files as the reference's TGCN_load
+    (fixture loader_toy.npz holds the file bytes and what the reference parsed)."""
+    fx = golden("loader_toy")
+    d = tmp_path / "toyset"
+    d.mkdir()
+    for n in ("train.txt", "test.txt", "user_item_tag.txt"):
+        (d / n).write_bytes(fx["files." + n].tobytes())
+    ld = T.data.TGCN_load(str(tmp_path), "toyset")
+    assert {k: int(v) for k, v in ld.num.items()} == {k[4:]: int(fx[k]) for k in fx if k.startswith("num.")}
+    for split in ("train", "test"):
+        e = ld.edge_index[split]
+        assert np.array_equal(e[np.lexsort((e[:, 1], e[:, 0]))], fx["edges." + split])
+        assert sum(len(v) for v in ld.user_items[split].values()) == len(e)
+    assert np.array_equal(ld.uit_data, fx["uit_data"])
+    for nm in ("ui_adj", "ut_adj", "it_adj"):
+        c = getattr(ld, nm)
+        assert tuple(c.shape) == tuple(fx[nm + ".shape"])
+        key = c.row.astype(np.int64) * c.shape[1] + c.col
+        uk, cnt = np.unique(key, return_counts=True)          # duplicates are summed when the adjacency is built
+        assert np.array_equal(uk, fx[nm + ".row"].astype(np.int64) * c.shape[1] + fx[nm + ".col"])
+        assert np.array_equal(cnt.astype(np.float32), fx[nm + ".data"])
+    # round trip through our own writer
+    T.data.write_dataset(ld, str(tmp_path), "again")
+    ld2 = T.data.TGCN_load(str(tmp_path), "again")
+    assert ld2.num == ld.num and np.array_equal(ld2.uit_data, ld.uit_data)
+
+
+def test_early_stop_protocol(tmp_path):
+    import types
+    cfg = T.get_config("lightgcn", patient_epoch=1)
+    es = T.Early_stop(types.SimpleNamespace(out_dir=str(tmp_path)), cfg)
+    model = torch.nn.Linear(2, 2)
+    assert es(model, {"ndcg": [0.5, 0.6]}, 0) is False and es.best_epoch == 0       # key ndcg -> NDCG@10 = first entry
+    assert (tmp_path / "model.pth.tar").exists()
+    assert es(model, {"ndcg": [0.4, 0.9]}, 5) is False and es.count_step == 1       # worse @10 although better @20
+    assert es(model, {"ndcg": [0.45, 0.9]}, 10) is True                             # count 2 > patient 1
+    assert es.best_result == {"ndcg": [0.5, 0.6]}
