@@ -109,7 +109,8 @@ class TransTag_training_data(Abstract_training_data):
         self.batch_size = cfg["transtag_batch"]
         self.num = data.num["item"]
         n_tag = data.num["tag"]
-        uit = torch.from_numpy(np.asarray(data.uit_data)).to(self.device, torch.int64)
+        uit = data.uit_data if isinstance(data.uit_data, torch.Tensor) else torch.from_numpy(np.asarray(data.uit_data))
+        uit = uit.to(self.device, torch.int64)
         self.uti = uit[:, [0, 2, 1]].contiguous()
         self._left = self.uti[:, 0] * n_tag + self.uti[:, 1]            # (u, t) pair id
         self._keys = torch.sort(self._left * self.num + self.uti[:, 2]).values

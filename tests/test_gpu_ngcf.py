@@ -23,8 +23,11 @@ def _model(fx, **kw):
     return m
 
 
-def _grad_close(got, want, name):
-    np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-6 * max(1e-3, float(np.abs(want).max())), err_msg=name)
+def _grad_close(got, want, name, scale=None):
+    """atol from `scale` = the largest gradient entry of the whole model when given: entries that are sums
+    cancelling to ~1e-7 carry absolute errors of the size of their terms."""
+    scale = float(np.abs(want).max()) if scale is None else scale
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-6 * max(1e-3, scale), err_msg=name)
 
 
 def test_state_dict_layout(golden):
@@ -47,9 +50,10 @@ def test_ngcf_forward_loss_grads_golden(golden, name):
     np.testing.assert_allclose([float(v) for v in lossx], fx["loss_parts"], rtol=1e-5, atol=1e-8)
     sum(lossx).backward()
     want = np.concatenate([fx[f"grad.embed.{t}"] for t in range(len(m.num_list))])
-    _grad_close(m.table.grad.cpu().numpy(), want, "table")
+    scale = max([float(np.abs(want).max())] + [float(np.abs(fx[f"grad.mat.{k}"]).max()) for k in m.mat])
+    _grad_close(m.table.grad.cpu().numpy(), want, "table", scale)
     for k, p in m.mat.items():
-        _grad_close(p.grad.cpu().numpy(), fx[f"grad.mat.{k}"], k)
+        _grad_close(p.grad.cpu().numpy(), fx[f"grad.mat.{k}"], k, scale)
 
 
 @pytest.mark.parametrize("name", ["ngcf_toy", "ngcf_med"])
@@ -79,9 +83,10 @@ def test_ngcf_unfused_path_matches_fused(golden):
     l1, l2 = m.loss(b), m2.loss(b)
     np.testing.assert_allclose([float(v) for v in l2], [float(v) for v in l1], rtol=1e-5)
     sum(l1).backward(); sum(l2).backward()
-    _grad_close(m2.table.grad.cpu().numpy(), m.table.grad.cpu().numpy(), "table")
+    scale = max([float(m.table.grad.abs().max())] + [float(m.mat[k].grad.abs().max()) for k in m.mat])
+    _grad_close(m2.table.grad.cpu().numpy(), m.table.grad.cpu().numpy(), "table", scale)
     for k in m.mat:
-        _grad_close(m2.mat[k].grad.cpu().numpy(), m.mat[k].grad.cpu().numpy(), k)
+        _grad_close(m2.mat[k].grad.cpu().numpy(), m.mat[k].grad.cpu().numpy(), k, scale)
 
 
 @pytest.mark.parametrize("din,dout", [(64, 64), (64, 32), (32, 16), (16, 64), (128, 64), (16, 16), (64, 128)])
