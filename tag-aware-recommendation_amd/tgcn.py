@@ -93,7 +93,11 @@ def _dense_block(st, U, q, p, wb, w1, w2, w3, Wf, bf):
     s = torch.relu(st @ U + q) @ p.t()                        # [n,3,1]
     e3 = torch.softmax(s, dim=1) * st                         # scaled, NOT summed
     # bit level: Conv2d(1, C, (3,1)) == a 3 -> C mix per feature
-    bit = torch.relu(torch.matmul(wb[:, 0, :, 0], e3)).reshape(n, -1)        # [n, C*D], channel-major
+    w = wb[:, 0, :, 0]                                         # [C, 3]
+    bit = e3[:, None, 0, :] * w[None, :, 0, None]              # three fused multiply-adds per output element,
+    bit = torch.addcmul(bit, e3[:, None, 1, :], w[None, :, 1, None])      # not a batch of 3-deep GEMMs
+    bit = torch.addcmul(bit, e3[:, None, 2, :], w[None, :, 2, None])
+    bit = torch.relu_(bit).reshape(n, -1)                      # [n, C*D], channel-major
     # vector level: Conv2d(1, V, (j, D)), j = 1..3 == dot products over j stacked rows
     flat = e3.reshape(n, 3 * D)
     v1 = torch.relu(torch.einsum("nhd,cd->nch", e3, w1[:, 0, 0, :])).reshape(n, -1)
