@@ -153,6 +153,18 @@ int tagrec_tgcn_attn_bwd_f32(const float* P, const float* Q, const float* WT, co
                              int64_t n, int k, int D, int A, int n_wt, float* dP, float* dQ, float* dEj,
                              float* dWT, float* dv, float* workspace, int64_t workspace_floats, void* stream);
 
+/* ---- TGCN type-level attention + bit/vector convolutions + fusion layer, fused (tgcn.py:78-106) ------------
+ * One node type per call.  T0/T1/T2 [n, D]: the (user-side, item-side, tag-side) vectors of each node, in
+ * that order.  U [D, A], q [A], p [A]; wb [C, 3] (Conv2d(1,C,(3,1)) weight); w1 [V, D], w2 [V, 2, D],
+ * w3 [V, 3, D] (Conv2d(1,V,(j,D)) weights); Wf [C*D + 6V, Dout], bf [Dout].
+ *   fwd: out [n, Dout] = relu(y Wf + bf) with y the convolution features of e_j = softmax_j(relu(t_j U + q).p) t_j;
+ *        bw_out [n, 3] = the softmax weights (kept for the backward pass).
+ * Built for A = 32, C = 32, V = 8 (the reference's defaults) and D, Dout in {16, 32, 64, 128}. */
+int tagrec_tgcn_fuse_fwd_f32(const float* T0, const float* T1, const float* T2, int64_t n, int D, int Dout,
+                             int A, int C, int V, const float* U, const float* q, const float* p,
+                             const float* wb, const float* w1, const float* w2, const float* w3,
+                             const float* Wf, const float* bf, float* bw_out, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,295 @@
+// K8: TGCN type-level attention + bit-/vector-level convolutions + fusion layer, fused, on the gfx950
+// matrix cores (exact-fp32 MFMA 16x16x4).
+//
+// Replaces `BasicLayer._atten2`, `_conv`, `_fusion` (/root/reference/model/tgcn.py:78-106) for one node type:
+//     s_j  = relu(t_j U + q) . p            j = 0..2 (user-, item-, tag-side vector of the node)
+//     e_j  = softmax_j(s)_j * t_j           (scaled, NOT summed)
+//     y    = [ relu(sum_j wb[c][j] e_j[d])  for c < 32, d < D          bit-level  Conv2d(1,32,(3,1))
+//            | relu(w1[c] . e_h)            c < 8, h < 3               vector-level Conv2d(1,8,(1,D))
+//            | relu(w2[c] . [e_h ; e_h+1])  c < 8, h < 2                             Conv2d(1,8,(2,D))
+//            | relu(w3[c] . [e_0;e_1;e_2])  c < 8 ]                                  Conv2d(1,8,(3,D))
+//     out  = relu(y Wf + bf)                Wf [32 D + 48, Dout]
+// The reference materialises y for ALL nodes (N x (32 D + 48) floats); here y exists only as the MFMA
+// B-operand of the step that consumes it.  MFMA-bound: 2 (32 D + 48) Dout flop per node.
+//
+// Register layout (everything is computed transposed, as in ngcf.hip): lane (r = lane & 15, q = lane >> 4)
+// owns, for node r of the wave's 16-node subtile, the contiguous quarter [q W/4, (q+1) W/4) of every
+// width-W vector (inputs, attention pre-activations, outputs).  With the MFMA "row" index i = 4 q' + v of
+// block b mapped to element q' W/4 + v W/16 + b, an accumulator is directly the next product's B-operand,
+// loads and stores are contiguous W-byte runs per lane, and the A-operand (weights, streamed from L2) of a
+// lane is W/16 consecutive floats per k-step.
+#include "common.h"
+
+namespace tagrec {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFuseThreads = 256;
+constexpr int kBitC = 32;      // num_bit_conv  (utility/config.py:44)
+constexpr int kVecC = 8;       // num_vec_conv  (utility/config.py:45)
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ float quad_sum(float v) {   // over the 4 lanes that share a node (q = 0..3)
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// N consecutive floats from p (N in {1,2,4,8}); p is N*4-byte aligned
+template <int N>
+__device__ __forceinline__ void load_run(const float* __restrict__ p, float (&a)[N]) {
+  if constexpr (N == 1) {
+    a[0] = p[0];
+  } else if constexpr (N == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    a[0] = t.x; a[1] = t.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + i);
+      a[i] = t.x; a[i + 1] = t.y; a[i + 2] = t.z; a[i + 3] = t.w;
+    }
+  }
+}
+
+// The lane's quarter of a width-W row: W/4 consecutive floats
+template <int SEG>
+__device__ __forceinline__ void load_seg(const float* __restrict__ p, bool ok, float (&a)[SEG]) {
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < SEG; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + i);
+      a[i] = t.x; a[i + 1] = t.y; a[i + 2] = t.z; a[i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+  }
+}
+
+// Type-level attention for one subtile: t[j][e] (e < D/4) -> softmax weights bw[j]; scales t in place.
+// Also returns the pre-activations sc[j][ab] (element a = q A/4 + v A/16 + ab) for the backward pass.
+template <int D, int A>
+__device__ __forceinline__ void type_attention(float (&t)[3][D / 4], const float* __restrict__ U,
+                                               const float* __restrict__ qv, const float* __restrict__ pv, int r, int q,
+                                               f32x4 (&sc)[3][A / 16], float (&bw)[3]) {
+  constexpr int DS = D / 4, AB = A / 16, AS = A / 4;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int ab = 0; ab < AB; ++ab) sc[j][ab] = zero4();
+  const float* urow = U + static_cast<int64_t>(q * DS) * A + r * AB;
+#pragma unroll
+  for (int e = 0; e < DS; ++e) {
+    float ua[AB];
+    load_run<AB>(urow + e * A, ua);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int ab = 0; ab < AB; ++ab) sc[j][ab] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[ab], t[j][e], sc[j][ab], 0, 0, 0);
+  }
+  float s[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float part = 0.f;
+#pragma unroll
+    for (int ab = 0; ab < AB; ++ab)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int a = q * AS + v * AB + ab;
+        sc[j][ab][v] += qv[a];
+        part = fmaf(fmaxf(sc[j][ab][v], 0.f), pv[a], part);
+      }
+    s[j] = quad_sum(part);
+  }
+  const float mx = fmaxf(s[0], fmaxf(s[1], s[2]));
+  const float e0 = expf(s[0] - mx), e1 = expf(s[1] - mx), e2 = expf(s[2] - mx);
+  const float inv = 1.0f / (e0 + e1 + e2);
+  bw[0] = e0 * inv; bw[1] = e1 * inv; bw[2] = e2 * inv;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int e = 0; e < DS; ++e) t[j][e] *= bw[j];
+}
+
+// Vector-level convolutions of one subtile through the matrix cores: the 8 filters sit on MFMA rows 0..7, so
+// lanes q = 0, 1 end up with filter c = 4 q + v in register v; six groups g: v1 h=0..2, v2 h=0..1, v3.
+// pre[g] holds the PRE-activation.
+template <int D>
+__device__ __forceinline__ void vector_conv(const float (&e3)[3][D / 4], const float* __restrict__ w1,
+                                            const float* __restrict__ w2, const float* __restrict__ w3, int r, int q,
+                                            f32x4 (&pre)[6]) {
+  constexpr int DS = D / 4;
+#pragma unroll
+  for (int g = 0; g < 6; ++g) pre[g] = zero4();
+  const bool row_ok = r < kVecC;
+  const int d0 = q * DS;
+#pragma unroll
+  for (int e = 0; e < DS; ++e) {
+    const float a1 = row_ok ? w1[r * D + d0 + e] : 0.f;
+    const float a20 = row_ok ? w2[(r * 2 + 0) * D + d0 + e] : 0.f;
+    const float a21 = row_ok ? w2[(r * 2 + 1) * D + d0 + e] : 0.f;
+    const float a30 = row_ok ? w3[(r * 3 + 0) * D + d0 + e] : 0.f;
+    const float a31 = row_ok ? w3[(r * 3 + 1) * D + d0 + e] : 0.f;
+    const float a32 = row_ok ? w3[(r * 3 + 2) * D + d0 + e] : 0.f;
+#pragma unroll
+    for (int h = 0; h < 3; ++h) pre[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e3[h][e], pre[h], 0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      pre[3 + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a20, e3[h][e], pre[3 + h], 0, 0, 0);
+      pre[3 + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a21, e3[h + 1][e], pre[3 + h], 0, 0, 0);
+    }
+    pre[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a30, e3[0][e], pre[5], 0, 0, 0);
+    pre[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a31, e3[1][e], pre[5], 0, 0, 0);
+    pre[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a32, e3[2][e], pre[5], 0, 0, 0);
+  }
+}
+
+// index of vector feature (group g, filter c) inside y, after the 32 D bit-level features
+__device__ __forceinline__ int vec_feature(int g, int c) {
+  if (g < 3) return c * 3 + g;                        // conv_1: [c][h]
+  if (g < 5) return 3 * kVecC + c * 2 + (g - 3);      // conv_2: [c][h]
+  return 5 * kVecC + c;                               // conv_3: [c]
+}
+
+// ---- forward -----------------------------------------------------------------------------------
+template <int D, int DOUT, int A, int NS>
+__global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_fwd_kernel(
+    const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, int64_t n,
+    const float* __restrict__ U, const float* __restrict__ qv, const float* __restrict__ pv,
+    const float* __restrict__ wb, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ w3, const float* __restrict__ Wf, const float* __restrict__ bf,
+    float* __restrict__ bw_out, float* __restrict__ out) {
+  constexpr int DS = D / 4, OS = DOUT / 4, OB = DOUT / 16, AB = A / 16;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (n + 16 * NS - 1) / (16 * NS);
+  const float* Tj[3] = {T0, T1, T2};
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * (kFuseThreads / 64) + (threadIdx.x >> 6); tile < n_tiles;
+       tile += static_cast<int64_t>(gridDim.x) * (kFuseThreads / 64)) {
+    float t[NS][3][DS];
+    int64_t node[NS];
+    bool ok[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      node[s] = (tile * NS + s) * 16 + r;
+      ok[s] = node[s] < n;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) load_seg<DS>(Tj[j] + node[s] * D + q * DS, ok[s], t[s][j]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      f32x4 sc[3][AB];
+      float bw[3];
+      type_attention<D, A>(t[s], U, qv, pv, r, q, sc, bw);
+      if (ok[s] && q == 0) {
+        bw_out[node[s] * 3 + 0] = bw[0];
+        bw_out[node[s] * 3 + 1] = bw[1];
+        bw_out[node[s] * 3 + 2] = bw[2];
+      }
+    }
+    f32x4 acc[NS][OB];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) acc[s][ob] = zero4();
+    // bit-level features: k = c D + q DS + e
+    for (int c = 0; c < kBitC; ++c) {
+      const float c0 = wb[c * 3], c1 = wb[c * 3 + 1], c2 = wb[c * 3 + 2];
+      const float* wrow = Wf + (static_cast<int64_t>(c) * D + q * DS) * DOUT + r * OB;
+#pragma unroll
+      for (int e = 0; e < DS; ++e) {
+        float a[OB];
+        load_run<OB>(wrow + e * DOUT, a);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const float y = fmaxf(fmaf(c0, t[s][0][e], fmaf(c1, t[s][1][e], c2 * t[s][2][e])), 0.f);
+#pragma unroll
+          for (int ob = 0; ob < OB; ++ob) acc[s][ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob], y, acc[s][ob], 0, 0, 0);
+        }
+      }
+    }
+    // vector-level features: group g, register v -> filter c = 4 q + v on lanes q < 2 (zero elsewhere)
+    {
+      f32x4 pre[NS][6];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) vector_conv<D>(t[s], w1, w2, w3, r, q, pre[s]);
+#pragma unroll
+      for (int g = 0; g < 6; ++g)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int f = vec_feature(g, 4 * (q & 1) + v);
+          float a[OB];
+          load_run<OB>(Wf + (static_cast<int64_t>(kBitC) * D + f) * DOUT + r * OB, a);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const float y = q < 2 ? fmaxf(pre[s][g][v], 0.f) : 0.f;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) acc[s][ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob], y, acc[s][ob], 0, 0, 0);
+          }
+        }
+    }
+    // epilogue: element o = q OS + v OB + ob
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (!ok[s]) continue;
+      float o[OS];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[v * OB + ob] = fmaxf(acc[s][ob][v] + bf[q * OS + v * OB + ob], 0.f);
+      float* dst = out + node[s] * DOUT + q * OS;
+#pragma unroll
+      for (int i = 0; i < OS; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+    }
+  }
+}
+
+template <int D, int DOUT>
+int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n, const float* U, const float* qv,
+                    const float* pv, const float* wb, const float* w1, const float* w2, const float* w3, const float* Wf,
+                    const float* bf, float* bw_out, float* out, hipStream_t s) {
+  constexpr int NS = (D >= 128) ? 1 : 2;
+  const int64_t tiles = (n + 16 * NS - 1) / (16 * NS);
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > 256 * 2) blocks = 256 * 2;
+  tgcn_fuse_fwd_kernel<D, DOUT, 32, NS><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
+      T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+#define TAGREC_FUSE_DISPATCH(CALL)                                                        \
+  switch (D * 1000 + Dout) {                                                              \
+    case 16016: return CALL(16, 16);   case 16032: return CALL(16, 32);                   \
+    case 16064: return CALL(16, 64);   case 16128: return CALL(16, 128);                  \
+    case 32016: return CALL(32, 16);   case 32032: return CALL(32, 32);                   \
+    case 32064: return CALL(32, 64);   case 32128: return CALL(32, 128);                  \
+    case 64016: return CALL(64, 16);   case 64032: return CALL(64, 32);                   \
+    case 64064: return CALL(64, 64);   case 64128: return CALL(64, 128);                  \
+    case 128016: return CALL(128, 16); case 128032: return CALL(128, 32);                 \
+    case 128064: return CALL(128, 64); case 128128: return CALL(128, 128);                \
+    default: break;                                                                       \
+  }                                                                                       \
+  return fail(TAGREC_E_UNSUPPORTED, "tgcn_fuse: D and Dout must be 16, 32, 64 or 128")
+
+}  // namespace tagrec
+
+using namespace tagrec;
+
+extern "C" int tagrec_tgcn_fuse_fwd_f32(const float* T0, const float* T1, const float* T2, int64_t n, int D, int Dout,
+                                        int A, int C, int V, const float* U, const float* q, const float* p,
+                                        const float* wb, const float* w1, const float* w2, const float* w3,
+                                        const float* Wf, const float* bf, float* bw_out, float* out, void* stream) {
+  TAGREC_REQUIRE(T0 && T1 && T2 && U && q && p && wb && w1 && w2 && w3 && Wf && bf && bw_out && out,
+                 "tgcn_fuse_fwd: null pointer");
+  if (A != 32 || C != kBitC || V != kVecC)
+    return fail(TAGREC_E_UNSUPPORTED, "tgcn_fuse: built for dim_atten 32, num_bit_conv 32, num_vec_conv 8");
+  TAGREC_REQUIRE(aligned16(T0) && aligned16(T1) && aligned16(T2) && aligned16(Wf) && aligned16(U) && aligned16(out),
+                 "tgcn_fuse_fwd: rows must be 16-byte aligned");
+  if (n <= 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(DD, OO) launch_fuse_fwd<DD, OO>(T0, T1, T2, n, U, q, p, wb, w1, w2, w3, Wf, bf, bw_out, out, s)
+  TAGREC_FUSE_DISPATCH(CALL);
+#undef CALL
+}

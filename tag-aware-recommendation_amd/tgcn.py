@@ -90,6 +90,9 @@ def _dense_block(st, U, q, p, wb, w1, w2, w3, Wf, bf):
     """Type-level attention -> bit-/vector-level convolutions -> fusion, for a chunk of rows.
     st [n, 3, D] = (user-side, item-side, tag-side) vectors of each node (tgcn.py:78-106)."""
     n, _, D = st.shape
+    q, p, bf = q.reshape(1, -1), p.reshape(1, -1), bf.reshape(1, -1)
+    wb = wb.reshape(wb.shape[0], 1, 3, 1)
+    w1, w2, w3 = w1.reshape(-1, 1, 1, D), w2.reshape(-1, 1, 2, D), w3.reshape(-1, 1, 3, D)
     s = torch.relu(st @ U + q) @ p.t()                        # [n,3,1]
     e3 = torch.softmax(s, dim=1) * st                         # scaled, NOT summed
     # bit level: Conv2d(1, C, (3,1)) == a 3 -> C mix per feature
@@ -106,6 +109,49 @@ def _dense_block(st, U, q, p, wb, w1, w2, w3, Wf, bf):
     v3 = torch.relu(flat @ w3.reshape(-1, 3 * D).t())
     y = torch.cat([bit, v1, v2, v3], dim=1)
     return torch.relu(y @ Wf + bf)
+
+
+def fused_dense_supported(D, Dout, A, C, V):
+    return A == 32 and C == 32 and V == 8 and D in (16, 32, 64, 128) and Dout in (16, 32, 64, 128)
+
+
+class _FusedDense(torch.autograd.Function):
+    """Type-level attention + convolutions + fusion layer as ONE HIP kernel (csrc/tgcn_fuse.hip); the
+    [n, 32 D + 48] convolution output is never written to memory."""
+
+    @staticmethod
+    def forward(ctx, t0, t1, t2, U, q, p, wb, w1, w2, w3, Wf, bf, chunk_rows):
+        t0, t1, t2 = t0.contiguous(), t1.contiguous(), t2.contiguous()
+        n, D = t0.shape
+        Dout = Wf.shape[1]
+        out = torch.empty(n, Dout, dtype=torch.float32, device=t0.device)
+        bw = torch.empty(n, 3, dtype=torch.float32, device=t0.device)
+        args = [x.contiguous() for x in (U, q, p, wb, w1, w2, w3, Wf, bf)]
+        _lib.check(_timed("fuse_fwd", _lib.load().tagrec_tgcn_fuse_fwd_f32, _lib.ptr(t0), _lib.ptr(t1), _lib.ptr(t2), n, D,
+                          Dout, U.shape[1], wb.shape[0], w1.shape[0], *[_lib.ptr(a) for a in args], _lib.ptr(bw),
+                          _lib.ptr(out), _lib.stream_ptr()), "tgcn_fuse_fwd")
+        ctx.save_for_backward(t0, t1, t2, U, q, p, wb, w1, w2, w3, Wf, bf, out, bw)
+        ctx.chunk_rows = chunk_rows
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        t0, t1, t2, U, q, p, wb, w1, w2, w3, Wf, bf, out, bw = ctx.saved_tensors
+        # interim backward: re-evaluate the block chunk by chunk in its operator form and differentiate that
+        prm = [x.detach().requires_grad_() for x in (U, q, p, wb, w1, w2, w3, Wf, bf)]
+        gt = [torch.empty_like(t0), torch.empty_like(t1), torch.empty_like(t2)]
+        gp = [torch.zeros_like(x) for x in prm]
+        for lo in range(0, t0.shape[0], ctx.chunk_rows):
+            hi = min(lo + ctx.chunk_rows, t0.shape[0])
+            ts = [x[lo:hi].detach().requires_grad_() for x in (t0, t1, t2)]
+            with torch.enable_grad():
+                o = _dense_block(torch.stack(ts, dim=1), *prm)
+            grads = torch.autograd.grad(o, ts + prm, d_out[lo:hi])
+            for k in range(3):
+                gt[k][lo:hi] = grads[k]
+            for k in range(len(prm)):
+                gp[k] += grads[3 + k]
+        return (*gt, *gp, None)
 
 
 class _Layer(nn.Module):
@@ -128,9 +174,16 @@ class _Layer(nn.Module):
         self.bf = nn.Parameter(torch.empty(1, out_features))
         self.in_features = in_features
 
-    def dense(self, st, chunk_rows, use_checkpoint):
+    def dense(self, trip, chunk_rows, use_checkpoint, fused=True):
         args = (self.U, self.q, self.p, self.conv["bit_level"].weight, self.conv["vec_level"]["conv_1"].weight,
                 self.conv["vec_level"]["conv_2"].weight, self.conv["vec_level"]["conv_3"].weight, self.Wf, self.bf)
+        if fused and fused_dense_supported(self.in_features, self.Wf.shape[1], self.U.shape[1], args[3].shape[0],
+                                           args[4].shape[0]):
+            U, q, p, wb, w1, w2, w3, Wf, bf = args
+            return _FusedDense.apply(trip[0], trip[1], trip[2], U, q.reshape(-1), p.reshape(-1), wb.reshape(wb.shape[0], 3),
+                                     w1.reshape(w1.shape[0], -1), w2.reshape(w2.shape[0], -1), w3.reshape(w3.shape[0], -1),
+                                     Wf, bf.reshape(-1), chunk_rows)
+        st = torch.stack(trip, dim=1)
         outs = []
         for lo in range(0, st.shape[0], chunk_rows):
             part = st[lo:lo + chunk_rows]
@@ -140,7 +193,7 @@ class _Layer(nn.Module):
                 outs.append(_dense_block(part, *args))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
-    def forward(self, eu, ei, et, ewp, nbr, chunk_rows, use_checkpoint):
+    def forward(self, eu, ei, et, ewp, nbr, chunk_rows, use_checkpoint, fused=True):
         D = self.in_features
         emb = {"user": eu, "item": ei, "tag": et}
         # per neighbour type: Q = e W2 and the weight look-up table, shared by the two relations it serves
@@ -158,7 +211,7 @@ class _Layer(nn.Module):
         et_u, et_i = att("tag", "user", t_u), att("tag", "item", t_i)
         outs = []
         for trip in ((eu, eu_i, eu_t), (ei_u, ei, ei_t), (et_u, et_i, et)):
-            outs.append(self.dense(torch.stack(trip, dim=1), chunk_rows, use_checkpoint))
+            outs.append(self.dense(trip, chunk_rows, use_checkpoint, fused))
         return outs
 
 
@@ -301,6 +354,7 @@ class TGCN(nn.Module):
         self.seed = config.get("seed", 2020)
         self.chunk_rows = config.get("tgcn_chunk_rows", 65536)
         self.use_checkpoint = config.get("tgcn_checkpoint", True)
+        self.fused_dense = config.get("tgcn_fused_dense", True)
 
     def train(self, mode=True):
         self._eval_cache = None
@@ -311,7 +365,7 @@ class TGCN(nn.Module):
         ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])          # index 0 = pad (tgcn.py:21-24)
         cu, ci, ct = [eu], [ei], [et]
         for i, layer in enumerate(self.layer.values()):
-            eu, ei, et = layer(eu, ei, et, ewp, self.nbr, self.chunk_rows, self.use_checkpoint)
+            eu, ei, et = layer(eu, ei, et, ewp, self.nbr, self.chunk_rows, self.use_checkpoint, self.fused_dense)
             p = self.message_drop_list[i]
             if self.training and p > 0:
                 eu, ei, et = (torch.nn.functional.dropout(t, p=p, training=True) for t in (eu, ei, et))

@@ -140,3 +140,46 @@ def test_neighbor_tables_semantics():
             assert got == {0}
     ids_ut, wts_ut = tabs[1]                       # user-tag: integer co-occurrence weights
     assert wts_ut.max() >= 1 and (wts_ut[ids_ut == 0] == 0).all()
+
+
+@pytest.mark.parametrize("D,Dout,n", [(16, 16, 100), (64, 32, 333), (128, 128, 257), (32, 64, 64), (64, 64, 31)])
+def test_fused_dense_block_vs_operator_form(D, Dout, n):
+    """csrc/tgcn_fuse.hip (type attention + convolutions + fusion in one kernel) against the same block
+    written operator by operator (fp64 on the host); ragged node counts; gradients through autograd."""
+    torch.manual_seed(D * 3 + Dout)
+    A, C, V = 32, 32, 8
+    ts = [torch.randn(n, D) * 0.5 for _ in range(3)]
+    prm = [torch.randn(D, A) * 0.2, torch.randn(1, A) * 0.1, torch.randn(1, A), torch.randn(C, 1, 3, 1) * 0.5,
+           torch.randn(V, 1, 1, D) * 0.2, torch.randn(V, 1, 2, D) * 0.2, torch.randn(V, 1, 3, D) * 0.2,
+           torch.randn(C * D + 6 * V, Dout) * 0.05, torch.randn(1, Dout) * 0.1]
+    up = torch.randn(n, Dout)
+    rt = [t.double().requires_grad_() for t in ts]
+    rp = [x.double().requires_grad_() for x in prm]
+    want = TG._dense_block(torch.stack(rt, dim=1), *rp)
+    (want * up.double()).sum().backward()
+    gt = [t.to(DEV).requires_grad_() for t in ts]
+    gp = [x.to(DEV).requires_grad_() for x in prm]
+    U, q, p, wb, w1, w2, w3, Wf, bf = gp
+    got = TG._FusedDense.apply(gt[0], gt[1], gt[2], U, q.reshape(-1), p.reshape(-1), wb.reshape(C, 3), w1.reshape(V, -1),
+                               w2.reshape(V, -1), w3.reshape(V, -1), Wf, bf.reshape(-1), 50)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().float().numpy(), rtol=1e-4, atol=2e-5)
+    (got * up.to(DEV)).sum().backward()
+    scale = max(float(x.grad.abs().max()) for x in rt + rp)
+    for name, a, b in [(f"t{k}", gt[k], rt[k]) for k in range(3)] + [(f"p{k}", gp[k], rp[k]) for k in range(len(prm))]:
+        _close(a.grad.cpu().numpy(), b.grad.float().numpy(), name, rtol=2e-3, scale=scale)
+
+
+def test_tgcn_fused_equals_operator_path(golden):
+    fx = golden("tgcn_toy")
+    b = torch.from_numpy(fx["batches"][0]).to(DEV)
+    res = []
+    for fused in (True, False):
+        m = _model(fx, tgcn_fused_dense=fused)
+        m.train()
+        lossx = m.loss(b)
+        sum(lossx).backward()
+        res.append(([float(v) for v in lossx], {k: p.grad.cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
+    scale = max(float(np.abs(v).max()) for v in res[1][1].values())
+    for k in res[1][1]:
+        _close(res[0][1][k], res[1][1][k], k, rtol=2e-3, scale=scale)
