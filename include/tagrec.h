@@ -165,6 +165,18 @@ int tagrec_tgcn_fuse_fwd_f32(const float* T0, const float* T1, const float* T2, 
                              const float* wb, const float* w1, const float* w2, const float* w3,
                              const float* Wf, const float* bf, float* bw_out, float* out, void* stream);
 
+/*   bwd (data part): from dOut [n, Dout] and the forward's `out` (ReLU mask): dT0/dT1/dT2 [n, D]; yvec [n, 6V]
+ *        (post-ReLU vector features) and dfeat [n, 6V] (their pre-activation gradients), dS [n, 3A] (type-attention
+ *        pre-activation gradients) for the weight gradients; small [3C + 2A + Dout] = dwb | dq | dp | dbf
+ *        (deterministic fold of per-block partials; workspace of tagrec_tgcn_fuse_bwd_workspace(Dout) floats). */
+int64_t tagrec_tgcn_fuse_bwd_workspace(int Dout);
+int tagrec_tgcn_fuse_bwd_f32(const float* T0, const float* T1, const float* T2, int64_t n, int D, int Dout,
+                             int A, int C, int V, const float* U, const float* q, const float* p,
+                             const float* wb, const float* w1, const float* w2, const float* w3,
+                             const float* Wf, const float* out, const float* dOut, float* dT0, float* dT1,
+                             float* dT2, float* yvec, float* dfeat, float* dS, float* small,
+                             float* workspace, int64_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

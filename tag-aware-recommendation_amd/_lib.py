@@ -50,6 +50,9 @@ _SIGNATURES = {
     "tagrec_tgcn_attn_fwd_f32": [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tagrec_tgcn_attn_bwd_f32": [c_void_p] * 9 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_int64, c_void_p],
     "tagrec_tgcn_fuse_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 12,
+    "tagrec_tgcn_fuse_bwd_workspace": [c_int],
+    "tagrec_tgcn_fuse_bwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 18
+                                + [c_int64, c_void_p],
     "tagrec_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int64,
                         c_void_p],
 }

@@ -259,6 +259,264 @@ int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n
   return TAGREC_OK;
 }
 
+
+// ---- backward, data part -------------------------------------------------------------------------
+// From dOut and the saved `out` (ReLU mask): gradients w.r.t. the three input vectors, plus what the weight
+// gradients need (kept small): yvec [n, 48] post-ReLU vector features, dfeat [n, 48] their pre-activation
+// gradients, dS [n, 3 A] type-attention pre-activation gradients.  The tiny parameter gradients that are plain
+// sums over nodes (dwb [32,3], dq [A], dp [A], dbf [Dout]) are accumulated per block in LDS and written as
+// per-block partials [block][96 + 2 A + Dout].
+template <int D, int DOUT, int A>
+__global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
+    const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, int64_t n,
+    const float* __restrict__ U, const float* __restrict__ qv, const float* __restrict__ pv,
+    const float* __restrict__ wb, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ w3, const float* __restrict__ Wf, const float* __restrict__ outv,
+    const float* __restrict__ dOut, float* __restrict__ dT0, float* __restrict__ dT1, float* __restrict__ dT2,
+    float* __restrict__ yvec, float* __restrict__ dfeat, float* __restrict__ dS, float* __restrict__ part) {
+  constexpr int DS = D / 4, OS = DOUT / 4, IB = D / 16, AB = A / 16, AS = A / 4;
+  constexpr int NSM = 3 * kBitC + 2 * A + DOUT;      // dwb | dq | dp | dbf
+  __shared__ float sh[NSM];
+  for (int i = threadIdx.x; i < NSM; i += kFuseThreads) sh[i] = 0.f;
+  __syncthreads();
+  float* sh_wb = sh;
+  float* sh_q = sh + 3 * kBitC;
+  float* sh_p = sh_q + A;
+  float* sh_bf = sh_p + A;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (n + 15) / 16;
+  const float* Tj[3] = {T0, T1, T2};
+  float* dTj[3] = {dT0, dT1, dT2};
+  // row of the weight matrices this lane feeds as MFMA A-operand when the OUTPUT rows are input features:
+  // row i = r of block b  <->  d = (r >> 2) DS + 4 b + (r & 3)
+  const int drow = (r >> 2) * DS + (r & 3);
+  float bf_acc[OS];
+#pragma unroll
+  for (int i = 0; i < OS; ++i) bf_acc[i] = 0.f;
+  float q_acc[AS], p_acc[AS];
+#pragma unroll
+  for (int i = 0; i < AS; ++i) { q_acc[i] = 0.f; p_acc[i] = 0.f; }
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * (kFuseThreads / 64) + (threadIdx.x >> 6); tile < n_tiles;
+       tile += static_cast<int64_t>(gridDim.x) * (kFuseThreads / 64)) {
+    const int64_t node = tile * 16 + r;
+    const bool ok = node < n;
+    float e3[3][DS];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) load_seg<DS>(Tj[j] + node * D + q * DS, ok, e3[j]);
+    f32x4 sc[3][AB];
+    float bw[3];
+    type_attention<D, A>(e3, U, qv, pv, r, q, sc, bw);       // e3 now holds softmax_j * t_j
+    // g = dOut * [out > 0], the lane's quarter of the Dout outputs
+    float g[OS];
+    {
+      float o[OS];
+      load_seg<OS>(dOut + node * DOUT + q * OS, ok, g);
+      load_seg<OS>(outv + node * DOUT + q * OS, ok, o);
+#pragma unroll
+      for (int i = 0; i < OS; ++i) {
+        g[i] = o[i] > 0.f ? g[i] : 0.f;
+        bf_acc[i] += g[i];
+      }
+    }
+    float de3[3][DS];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < DS; ++e) de3[j][e] = 0.f;
+    // bit-level: dy^T[d][node] = sum_o Wf[c D + d][o] g[node][o], then through the ReLU and the 3 -> 1 mix
+    for (int c = 0; c < kBitC; ++c) {
+      const float c0 = wb[c * 3], c1 = wb[c * 3 + 1], c2 = wb[c * 3 + 2];
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      const float* wrow = Wf + (static_cast<int64_t>(c) * D + drow) * DOUT + q * OS;
+#pragma unroll
+      for (int b = 0; b < IB; ++b) {
+        float a[OS];
+        load_run<OS>(wrow + static_cast<int64_t>(4 * b) * DOUT, a);
+        f32x4 dy = zero4();
+#pragma unroll
+        for (int t = 0; t < OS; ++t) dy = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], g[t], dy, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int e = 4 * b + v;
+          const float pre = fmaf(c0, e3[0][e], fmaf(c1, e3[1][e], c2 * e3[2][e]));
+          const float dp_ = pre > 0.f ? dy[v] : 0.f;
+          de3[0][e] = fmaf(c0, dp_, de3[0][e]);
+          de3[1][e] = fmaf(c1, dp_, de3[1][e]);
+          de3[2][e] = fmaf(c2, dp_, de3[2][e]);
+          a0 = fmaf(dp_, e3[0][e], a0);
+          a1 = fmaf(dp_, e3[1][e], a1);
+          a2 = fmaf(dp_, e3[2][e], a2);
+        }
+      }
+      // dwb[c][j] += sum over the wave (rows past n contribute 0: their g is 0)
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+      if (lane == 0) { atomicAdd(&sh_wb[c * 3], a0); atomicAdd(&sh_wb[c * 3 + 1], a1); atomicAdd(&sh_wb[c * 3 + 2], a2); }
+    }
+    // vector-level: recompute pre-activations, gradient of the 48 features, then back to de3
+    {
+      f32x4 pre[6];
+      vector_conv<D>(e3, w1, w2, w3, r, q, pre);
+      f32x4 dpv[6];
+#pragma unroll
+      for (int gi = 0; gi < 6; ++gi) {
+        // rows of this product are filters: lane r < 8 feeds Wf row of feature (gi, r)
+        const int f = vec_feature(gi, r & 7);
+        float a[OS];
+        load_run<OS>(Wf + (static_cast<int64_t>(kBitC) * D + f) * DOUT + q * OS, a);
+        f32x4 dy = zero4();
+#pragma unroll
+        for (int t = 0; t < OS; ++t) dy = __builtin_amdgcn_mfma_f32_16x16x4f32(r < kVecC ? a[t] : 0.f, g[t], dy, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const bool live = q < 2;
+          const float y = live ? fmaxf(pre[gi][v], 0.f) : 0.f;
+          dpv[gi][v] = (live && pre[gi][v] > 0.f) ? dy[v] : 0.f;
+          if (ok && live) {
+            const int ff = vec_feature(gi, 4 * q + v);
+            yvec[node * (6 * kVecC) + ff] = y;
+            dfeat[node * (6 * kVecC) + ff] = dpv[gi][v];
+          }
+        }
+      }
+      // de3_h[d] += sum_c w[c][a][d] dpre[c]: contraction over the 8 filters = 4 k-steps' worth in 2 live slots
+#pragma unroll
+      for (int b = 0; b < IB; ++b) {
+        const int d = drow + 4 * b;
+        f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = 4 * (q & 1) + v;                 // filter fed by this k-slot (slots 2,3 carry zeros)
+          const float z = q < 2 ? 1.f : 0.f;
+          const float k1 = z * w1[c * D + d];
+          const float k20 = z * w2[(c * 2 + 0) * D + d], k21 = z * w2[(c * 2 + 1) * D + d];
+          const float k30 = z * w3[(c * 3 + 0) * D + d], k31 = z * w3[(c * 3 + 1) * D + d], k32 = z * w3[(c * 3 + 2) * D + d];
+          // conv_1: feature (h) touches e3_h
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, dpv[0][v], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, dpv[1][v], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, dpv[2][v], acc2, 0, 0, 0);
+          // conv_2: window h covers rows h (tap 0) and h+1 (tap 1)
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k20, dpv[3][v], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k21, dpv[3][v], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k20, dpv[4][v], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(k21, dpv[4][v], acc2, 0, 0, 0);
+          // conv_3: one window over rows 0,1,2
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k30, dpv[5][v], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k31, dpv[5][v], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(k32, dpv[5][v], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          de3[0][4 * b + v] += acc0[v];
+          de3[1][4 * b + v] += acc1[v];
+          de3[2][4 * b + v] += acc2[v];
+        }
+      }
+    }
+    // through e_j = bw_j t_j and the type-level softmax
+    float tj[3][DS];
+    float db[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      load_seg<DS>(Tj[j] + node * D + q * DS, ok, tj[j]);
+      float s_ = 0.f;
+#pragma unroll
+      for (int e = 0; e < DS; ++e) s_ = fmaf(de3[j][e], tj[j][e], s_);
+      db[j] = quad_sum(s_);
+    }
+    const float mix = bw[0] * db[0] + bw[1] * db[1] + bw[2] * db[2];
+    float dsv[3][AS];                                        // dS_j[a] in the lane's quarter, order t = v AB + ab
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float ds = bw[j] * (db[j] - mix);
+#pragma unroll
+      for (int ab = 0; ab < AB; ++ab)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int t = v * AB + ab;
+          const float h = sc[j][ab][v];
+          const float x = h > 0.f ? ds * pv[q * AS + t] : 0.f;
+          dsv[j][t] = x;
+          q_acc[t] += x;
+          p_acc[t] = fmaf(ds, fmaxf(h, 0.f), p_acc[t]);
+        }
+      if (ok) {
+        float* dst = dS + node * (3 * A) + j * A + q * AS;
+#pragma unroll
+        for (int t = 0; t < AS; t += 4) *reinterpret_cast<float4*>(dst + t) = make_float4(dsv[j][t], dsv[j][t + 1], dsv[j][t + 2], dsv[j][t + 3]);
+      }
+    }
+    // dt_j = bw_j de3_j + U dS_j
+#pragma unroll
+    for (int b = 0; b < IB; ++b) {
+      float ua[AS];
+      load_run<AS>(U + static_cast<int64_t>(drow + 4 * b) * A + q * AS, ua);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int t = 0; t < AS; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t], dsv[j][t], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) de3[j][4 * b + v] = fmaf(bw[j], de3[j][4 * b + v], acc[v]);
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float* dst = dTj[j] + node * D + q * DS;
+#pragma unroll
+        for (int e = 0; e < DS; e += 4) *reinterpret_cast<float4*>(dst + e) = make_float4(de3[j][e], de3[j][e + 1], de3[j][e + 2], de3[j][e + 3]);
+      }
+    }
+  }
+  // fold the per-lane sums over the 16 node lanes, then into LDS
+#pragma unroll
+  for (int i = 0; i < OS; ++i) {
+    float v = bf_acc[i];
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    if (r == 0) atomicAdd(&sh_bf[q * OS + i], v);
+  }
+#pragma unroll
+  for (int i = 0; i < AS; ++i) {
+    float a = q_acc[i], b = p_acc[i];
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+    b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4); b += __shfl_xor(b, 8);
+    if (r == 0) { atomicAdd(&sh_q[q * AS + i], a); atomicAdd(&sh_p[q * AS + i], b); }
+  }
+  __syncthreads();
+  float* o = part + static_cast<int64_t>(blockIdx.x) * NSM;
+  for (int i = threadIdx.x; i < NSM; i += kFuseThreads) o[i] = sh[i];
+}
+
+__global__ void fuse_fold_kernel(const float* __restrict__ part, int n_parts, int elems, float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  float s = 0.f;
+  for (int b = 0; b < n_parts; ++b) s += part[static_cast<int64_t>(b) * elems + e];
+  out[e] = s;
+}
+
+constexpr int kFuseBwdBlocks = 512;
+
+template <int D, int DOUT>
+int launch_fuse_bwd(const float* T0, const float* T1, const float* T2, int64_t n, const float* U, const float* qv,
+                    const float* pv, const float* wb, const float* w1, const float* w2, const float* w3, const float* Wf,
+                    const float* outv, const float* dOut, float* dT0, float* dT1, float* dT2, float* yvec, float* dfeat,
+                    float* dS, float* small, float* ws, hipStream_t s) {
+  constexpr int A = 32;
+  constexpr int NSM = 3 * kBitC + 2 * A + DOUT;
+  const int64_t tiles = (n + 15) / 16;
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > kFuseBwdBlocks) blocks = kFuseBwdBlocks;
+  tgcn_fuse_bwd_kernel<D, DOUT, A><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
+      T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, outv, dOut, dT0, dT1, dT2, yvec, dfeat, dS, ws);
+  TAGREC_LAUNCH_CHECK();
+  fuse_fold_kernel<<<(NSM + 255) / 256, 256, 0, s>>>(ws, static_cast<int>(blocks), NSM, small);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
 #define TAGREC_FUSE_DISPATCH(CALL)                                                        \
   switch (D * 1000 + Dout) {                                                              \
     case 16016: return CALL(16, 16);   case 16032: return CALL(16, 32);                   \
@@ -290,6 +548,31 @@ extern "C" int tagrec_tgcn_fuse_fwd_f32(const float* T0, const float* T1, const 
   if (n <= 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(DD, OO) launch_fuse_fwd<DD, OO>(T0, T1, T2, n, U, q, p, wb, w1, w2, w3, Wf, bf, bw_out, out, s)
+  TAGREC_FUSE_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int64_t tagrec_tgcn_fuse_bwd_workspace(int Dout) {
+  return static_cast<int64_t>(kFuseBwdBlocks) * (3 * kBitC + 2 * 32 + Dout);
+}
+
+extern "C" int tagrec_tgcn_fuse_bwd_f32(const float* T0, const float* T1, const float* T2, int64_t n, int D, int Dout,
+                                        int A, int C, int V, const float* U, const float* q, const float* p,
+                                        const float* wb, const float* w1, const float* w2, const float* w3,
+                                        const float* Wf, const float* out, const float* dOut, float* dT0, float* dT1,
+                                        float* dT2, float* yvec, float* dfeat, float* dS, float* small,
+                                        float* workspace, int64_t workspace_floats, void* stream) {
+  TAGREC_REQUIRE(T0 && T1 && T2 && U && q && p && wb && w1 && w2 && w3 && Wf && out && dOut && dT0 && dT1 && dT2 && yvec &&
+                     dfeat && dS && small && workspace, "tgcn_fuse_bwd: null pointer");
+  if (A != 32 || C != kBitC || V != kVecC)
+    return fail(TAGREC_E_UNSUPPORTED, "tgcn_fuse: built for dim_atten 32, num_bit_conv 32, num_vec_conv 8");
+  TAGREC_REQUIRE(workspace_floats >= tagrec_tgcn_fuse_bwd_workspace(Dout), "tgcn_fuse_bwd: workspace too small");
+  TAGREC_REQUIRE(aligned16(T0) && aligned16(T1) && aligned16(T2) && aligned16(Wf) && aligned16(U) && aligned16(out) &&
+                     aligned16(dOut) && aligned16(dT0) && aligned16(dT1) && aligned16(dT2) && aligned16(dS),
+                 "tgcn_fuse_bwd: rows must be 16-byte aligned");
+  if (n <= 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(DD, OO) launch_fuse_bwd<DD, OO>(T0, T1, T2, n, U, q, p, wb, w1, w2, w3, Wf, out, dOut, dT0, dT1, dT2, yvec, dfeat, dS, small, workspace, s)
   TAGREC_FUSE_DISPATCH(CALL);
 #undef CALL
 }

@@ -137,21 +137,43 @@ class _FusedDense(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         t0, t1, t2, U, q, p, wb, w1, w2, w3, Wf, bf, out, bw = ctx.saved_tensors
-        # interim backward: re-evaluate the block chunk by chunk in its operator form and differentiate that
-        prm = [x.detach().requires_grad_() for x in (U, q, p, wb, w1, w2, w3, Wf, bf)]
-        gt = [torch.empty_like(t0), torch.empty_like(t1), torch.empty_like(t2)]
-        gp = [torch.zeros_like(x) for x in prm]
-        for lo in range(0, t0.shape[0], ctx.chunk_rows):
-            hi = min(lo + ctx.chunk_rows, t0.shape[0])
-            ts = [x[lo:hi].detach().requires_grad_() for x in (t0, t1, t2)]
-            with torch.enable_grad():
-                o = _dense_block(torch.stack(ts, dim=1), *prm)
-            grads = torch.autograd.grad(o, ts + prm, d_out[lo:hi])
-            for k in range(3):
-                gt[k][lo:hi] = grads[k]
-            for k in range(len(prm)):
-                gp[k] += grads[3 + k]
-        return (*gt, *gp, None)
+        n, D = t0.shape
+        Dout, A, C, V = Wf.shape[1], U.shape[1], wb.shape[0], w1.shape[0]
+        dev = t0.device
+        lib = _lib.load()
+        d_out = d_out.contiguous()
+        dts = [torch.empty_like(t0) for _ in range(3)]
+        yvec = torch.empty(n, 6 * V, dtype=torch.float32, device=dev)
+        dfeat = torch.empty(n, 6 * V, dtype=torch.float32, device=dev)
+        dS = torch.empty(n, 3 * A, dtype=torch.float32, device=dev)
+        small = torch.empty(3 * C + 2 * A + Dout, dtype=torch.float32, device=dev)
+        ws_n = lib.tagrec_tgcn_fuse_bwd_workspace(Dout)
+        ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+        _lib.check(_timed("fuse_bwd", lib.tagrec_tgcn_fuse_bwd_f32, _lib.ptr(t0), _lib.ptr(t1), _lib.ptr(t2), n, D, Dout, A, C,
+                          V, _lib.ptr(U), _lib.ptr(q), _lib.ptr(p), _lib.ptr(wb), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(w3),
+                          _lib.ptr(Wf), _lib.ptr(out), _lib.ptr(d_out), _lib.ptr(dts[0]), _lib.ptr(dts[1]), _lib.ptr(dts[2]),
+                          _lib.ptr(yvec), _lib.ptr(dfeat), _lib.ptr(dS), _lib.ptr(small), _lib.ptr(ws), ws_n,
+                          _lib.stream_ptr()), "tgcn_fuse_bwd")
+        dwb, dq, dp, dbf = small[:3 * C].reshape(C, 3), small[3 * C:3 * C + A], small[3 * C + A:3 * C + 2 * A], small[3 * C + 2 * A:]
+        # weight gradients that are plain GEMMs over the node axis
+        ts = (t0, t1, t2)
+        dU = sum(ts[j].t() @ dS[:, j * A:(j + 1) * A] for j in range(3))
+        e3 = [bw[:, j:j + 1] * ts[j] for j in range(3)]
+        f1, f2, f3 = dfeat[:, :3 * V].reshape(n, V, 3), dfeat[:, 3 * V:5 * V].reshape(n, V, 2), dfeat[:, 5 * V:]
+        dw1 = sum(f1[:, :, h].t() @ e3[h] for h in range(3))
+        dw2 = torch.stack([sum(f2[:, :, h].t() @ e3[h + a] for h in range(2)) for a in range(2)], dim=1).reshape(V, -1)
+        dw3 = torch.stack([f3.t() @ e3[a] for a in range(3)], dim=1).reshape(V, -1)
+        # fusion weight: dWf = y^T g, y re-formed chunk by chunk (interim; a dedicated kernel replaces this)
+        g = d_out * (out > 0)
+        dWf = torch.zeros_like(Wf)
+        for lo in range(0, n, ctx.chunk_rows):
+            hi = min(lo + ctx.chunk_rows, n)
+            bit = e3[0][lo:hi, None, :] * wb[None, :, 0, None]
+            bit = torch.addcmul(bit, e3[1][lo:hi, None, :], wb[None, :, 1, None])
+            bit = torch.addcmul(bit, e3[2][lo:hi, None, :], wb[None, :, 2, None])
+            y = torch.cat([torch.relu_(bit).reshape(hi - lo, -1), yvec[lo:hi]], dim=1)
+            dWf.addmm_(y.t(), g[lo:hi])
+        return (*dts, dU, dq, dp, dwb, dw1, dw2, dw3, dWf, dbf, None)
 
 
 class _Layer(nn.Module):
