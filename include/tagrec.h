@@ -167,7 +167,7 @@ int tagrec_tgcn_fuse_fwd_f32(const float* T0, const float* T1, const float* T2, 
 
 /*   bwd (data part): from dOut [n, Dout] and the forward's `out` (ReLU mask): dT0/dT1/dT2 [n, D]; yvec [n, 6V]
  *        (post-ReLU vector features) and dfeat [n, 6V] (their pre-activation gradients), dS [n, 3A] (type-attention
- *        pre-activation gradients) for the weight gradients; small [3C + 2A + Dout] = dwb | dq | dp | dbf
+ *        pre-activation gradients) for the weight gradients; small [3C + 2A] = dwb | dq | dp
  *        (deterministic fold of per-block partials; workspace of tagrec_tgcn_fuse_bwd_workspace(Dout) floats). */
 int64_t tagrec_tgcn_fuse_bwd_workspace(int Dout);
 int tagrec_tgcn_fuse_bwd_f32(const float* T0, const float* T1, const float* T2, int64_t n, int D, int Dout,
@@ -176,6 +176,14 @@ int tagrec_tgcn_fuse_bwd_f32(const float* T0, const float* T1, const float* T2, 
                              const float* Wf, const float* out, const float* dOut, float* dT0, float* dT1,
                              float* dT2, float* yvec, float* dfeat, float* dS, float* small,
                              float* workspace, int64_t workspace_floats, void* stream);
+
+/*   wf: dWf [C*D + 6V, Dout] = y^T (dOut * [out > 0]) with y re-formed on the fly from T0..T2, the saved softmax
+ *        weights bw [n, 3], wb and the yvec written by the data part (workspace of
+ *        tagrec_tgcn_fuse_wf_workspace(D, Dout) floats; deterministic fold of per-node-group partials). */
+int64_t tagrec_tgcn_fuse_wf_workspace(int D, int Dout);
+int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, const float* bw, const float* yvec,
+                            const float* wb, const float* out, const float* dOut, int64_t n, int D, int Dout,
+                            int C, int V, float* dWf, float* workspace, int64_t workspace_floats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,13 @@ __device__ __forceinline__ float quad_sum(float v) {   // over the 4 lanes that 
   return v;
 }
 
+// Launder a (wave-uniform) pointer inside the tile loop: without it the compiler proves the weight loads
+// loop-invariant, hoists hundreds of them out of the loop and holds them in registers (spilling the rest).
+__device__ __forceinline__ const float* fresh(const float* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 // N consecutive floats from p (N in {1,2,4,8}); p is N*4-byte aligned
 template <int N>
 __device__ __forceinline__ void load_run(const float* __restrict__ p, float (&a)[N]) {
@@ -87,6 +94,7 @@ __device__ __forceinline__ void type_attention(float (&t)[3][D / 4], const float
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int ab = 0; ab < AB; ++ab) sc[j][ab] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[ab], t[j][e], sc[j][ab], 0, 0, 0);
+    if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
   float s[3];
 #pragma unroll
@@ -142,6 +150,7 @@ __device__ __forceinline__ void vector_conv(const float (&e3)[3][D / 4], const f
     pre[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a30, e3[0][e], pre[5], 0, 0, 0);
     pre[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a31, e3[1][e], pre[5], 0, 0, 0);
     pre[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a32, e3[2][e], pre[5], 0, 0, 0);
+    if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled loop from hoisting every weight load
   }
 }
 
@@ -167,6 +176,8 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_fwd_kernel(
   const float* Tj[3] = {T0, T1, T2};
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * (kFuseThreads / 64) + (threadIdx.x >> 6); tile < n_tiles;
        tile += static_cast<int64_t>(gridDim.x) * (kFuseThreads / 64)) {
+    U = fresh(U); qv = fresh(qv); pv = fresh(pv); wb = fresh(wb); w1 = fresh(w1); w2 = fresh(w2); w3 = fresh(w3);
+    Wf = fresh(Wf); bf = fresh(bf);
     float t[NS][3][DS];
     int64_t node[NS];
     bool ok[NS];
@@ -264,8 +275,8 @@ int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n
 // From dOut and the saved `out` (ReLU mask): gradients w.r.t. the three input vectors, plus what the weight
 // gradients need (kept small): yvec [n, 48] post-ReLU vector features, dfeat [n, 48] their pre-activation
 // gradients, dS [n, 3 A] type-attention pre-activation gradients.  The tiny parameter gradients that are plain
-// sums over nodes (dwb [32,3], dq [A], dp [A], dbf [Dout]) are accumulated per block in LDS and written as
-// per-block partials [block][96 + 2 A + Dout].
+// sums over nodes (dwb [32,3], dq [A], dp [A]) are accumulated per block in LDS and written as
+// per-block partials [block][96 + 2 A]; dbf is a column sum the caller takes.
 template <int D, int DOUT, int A>
 __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
     const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, int64_t n,
@@ -275,14 +286,13 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
     const float* __restrict__ dOut, float* __restrict__ dT0, float* __restrict__ dT1, float* __restrict__ dT2,
     float* __restrict__ yvec, float* __restrict__ dfeat, float* __restrict__ dS, float* __restrict__ part) {
   constexpr int DS = D / 4, OS = DOUT / 4, IB = D / 16, AB = A / 16, AS = A / 4;
-  constexpr int NSM = 3 * kBitC + 2 * A + DOUT;      // dwb | dq | dp | dbf
+  constexpr int NSM = 3 * kBitC + 2 * A;             // dwb | dq | dp
   __shared__ float sh[NSM];
   for (int i = threadIdx.x; i < NSM; i += kFuseThreads) sh[i] = 0.f;
   __syncthreads();
   float* sh_wb = sh;
   float* sh_q = sh + 3 * kBitC;
   float* sh_p = sh_q + A;
-  float* sh_bf = sh_p + A;
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int64_t n_tiles = (n + 15) / 16;
@@ -291,14 +301,13 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
   // row of the weight matrices this lane feeds as MFMA A-operand when the OUTPUT rows are input features:
   // row i = r of block b  <->  d = (r >> 2) DS + 4 b + (r & 3)
   const int drow = (r >> 2) * DS + (r & 3);
-  float bf_acc[OS];
-#pragma unroll
-  for (int i = 0; i < OS; ++i) bf_acc[i] = 0.f;
   float q_acc[AS], p_acc[AS];
 #pragma unroll
   for (int i = 0; i < AS; ++i) { q_acc[i] = 0.f; p_acc[i] = 0.f; }
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * (kFuseThreads / 64) + (threadIdx.x >> 6); tile < n_tiles;
        tile += static_cast<int64_t>(gridDim.x) * (kFuseThreads / 64)) {
+    U = fresh(U); qv = fresh(qv); pv = fresh(pv); wb = fresh(wb); w1 = fresh(w1); w2 = fresh(w2); w3 = fresh(w3);
+    Wf = fresh(Wf);
     const int64_t node = tile * 16 + r;
     const bool ok = node < n;
     float e3[3][DS];
@@ -314,10 +323,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
       load_seg<OS>(dOut + node * DOUT + q * OS, ok, g);
       load_seg<OS>(outv + node * DOUT + q * OS, ok, o);
 #pragma unroll
-      for (int i = 0; i < OS; ++i) {
-        g[i] = o[i] > 0.f ? g[i] : 0.f;
-        bf_acc[i] += g[i];
-      }
+      for (int i = 0; i < OS; ++i) g[i] = o[i] > 0.f ? g[i] : 0.f;
     }
     float de3[3][DS];
 #pragma unroll
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
           a1 = fmaf(dp_, e3[1][e], a1);
           a2 = fmaf(dp_, e3[2][e], a2);
         }
+        __builtin_amdgcn_sched_barrier(0);      // bound the live weight rows: one block of loads at a time
       }
       // dwb[c][j] += sum over the wave (rows past n contribute 0: their g is 0)
 #pragma unroll
@@ -379,6 +386,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
             dfeat[node * (6 * kVecC) + ff] = dpv[gi][v];
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // de3_h[d] += sum_c w[c][a][d] dpre[c]: contraction over the 8 filters = 4 k-steps' worth in 2 live slots
 #pragma unroll
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
           de3[1][4 * b + v] += acc1[v];
           de3[2][4 * b + v] += acc2[v];
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // through e_j = bw_j t_j and the type-level softmax
@@ -460,6 +469,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
 #pragma unroll
         for (int v = 0; v < 4; ++v) de3[j][4 * b + v] = fmaf(bw[j], de3[j][4 * b + v], acc[v]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (ok) {
 #pragma unroll
@@ -471,12 +481,6 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
     }
   }
   // fold the per-lane sums over the 16 node lanes, then into LDS
-#pragma unroll
-  for (int i = 0; i < OS; ++i) {
-    float v = bf_acc[i];
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-    if (r == 0) atomicAdd(&sh_bf[q * OS + i], v);
-  }
 #pragma unroll
   for (int i = 0; i < AS; ++i) {
     float a = q_acc[i], b = p_acc[i];
@@ -505,7 +509,7 @@ int launch_fuse_bwd(const float* T0, const float* T1, const float* T2, int64_t n
                     const float* outv, const float* dOut, float* dT0, float* dT1, float* dT2, float* yvec, float* dfeat,
                     float* dS, float* small, float* ws, hipStream_t s) {
   constexpr int A = 32;
-  constexpr int NSM = 3 * kBitC + 2 * A + DOUT;
+  constexpr int NSM = 3 * kBitC + 2 * A;
   const int64_t tiles = (n + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;
   if (blocks > kFuseBwdBlocks) blocks = kFuseBwdBlocks;
@@ -513,6 +517,108 @@ int launch_fuse_bwd(const float* T0, const float* T1, const float* T2, int64_t n
       T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, outv, dOut, dT0, dT1, dT2, yvec, dfeat, dS, ws);
   TAGREC_LAUNCH_CHECK();
   fuse_fold_kernel<<<(NSM + 255) / 256, 256, 0, s>>>(ws, static_cast<int>(blocks), NSM, small);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+
+// ---- backward, fusion weight: dWf[k][o] = sum_nodes y[node][k] g[node][o] ---------------------------
+// y is re-formed on the fly (it is never stored): here the contraction runs over nodes, so node rows sit on the
+// MFMA k axis and both operands are read straight from global memory in their natural layout.
+// grid = (9 k-groups) x (node groups): k-group < 8 = four bit-level channels (one per wave, a full D x Dout
+// accumulator tile each), k-group 8 = the 48 vector-level rows (16 per wave).  Per-node-group partial sums are
+// folded in group order by fuse_fold_kernel (deterministic).
+template <int D, int DOUT>
+__global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
+    const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, const float* __restrict__ bw,
+    const float* __restrict__ yvec, const float* __restrict__ wb, const float* __restrict__ outv,
+    const float* __restrict__ dOut, int64_t n, int64_t rows_per_group, float* __restrict__ part) {
+  constexpr int IB = D / 16, OB = DOUT / 16;
+  constexpr int64_t KROWS = static_cast<int64_t>(kBitC) * D + 6 * kVecC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const int kg = blockIdx.x % 9;
+  const int64_t ng = blockIdx.x / 9;
+  const int64_t lo = ng * rows_per_group;
+  const int64_t hi = (lo + rows_per_group < n) ? lo + rows_per_group : n;
+  float* dst = part + ng * KROWS * DOUT;
+  if (kg < 8) {
+    const int c = 4 * kg + wave;
+    const float c0 = wb[c * 3], c1 = wb[c * 3 + 1], c2 = wb[c * 3 + 2];
+    f32x4 acc[IB][OB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int o = 0; o < OB; ++o) acc[i][o] = zero4();
+    for (int64_t node0 = lo; node0 < hi; node0 += 4) {
+      const int64_t node = node0 + q;
+      const bool ok = node < hi;
+      float y[IB], g[OB];
+      const float b0 = ok ? bw[node * 3] : 0.f, b1 = ok ? bw[node * 3 + 1] : 0.f, b2 = ok ? bw[node * 3 + 2] : 0.f;
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        const int64_t off = node * D + i * 16 + m;
+        // same operation order as the forward kernel, so the ReLU mask is the forward's
+        const float e0 = ok ? T0[off] * b0 : 0.f, e1 = ok ? T1[off] * b1 : 0.f, e2 = ok ? T2[off] * b2 : 0.f;
+        y[i] = fmaxf(fmaf(c0, e0, fmaf(c1, e1, c2 * e2)), 0.f);
+      }
+#pragma unroll
+      for (int o = 0; o < OB; ++o) {
+        const int64_t off = node * DOUT + o * 16 + m;
+        g[o] = (ok && outv[off] > 0.f) ? dOut[off] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int o = 0; o < OB; ++o) acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[i], g[o], acc[i][o], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int o = 0; o < OB; ++o)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          dst[(static_cast<int64_t>(c) * D + i * 16 + q * 4 + v) * DOUT + o * 16 + m] = acc[i][o][v];
+  } else if (wave < 3) {
+    f32x4 acc[OB];
+#pragma unroll
+    for (int o = 0; o < OB; ++o) acc[o] = zero4();
+    for (int64_t node0 = lo; node0 < hi; node0 += 4) {
+      const int64_t node = node0 + q;
+      const bool ok = node < hi;
+      const float y = ok ? yvec[node * (6 * kVecC) + wave * 16 + m] : 0.f;
+#pragma unroll
+      for (int o = 0; o < OB; ++o) {
+        const int64_t off = node * DOUT + o * 16 + m;
+        const float g = (ok && outv[off] > 0.f) ? dOut[off] : 0.f;
+        acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(y, g, acc[o], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        dst[(static_cast<int64_t>(kBitC) * D + wave * 16 + q * 4 + v) * DOUT + o * 16 + m] = acc[o][v];
+  }
+}
+
+constexpr int kWfGroups = 28;        // 9 x 28 = 252 blocks: one 4-wave block per CU
+
+template <int D, int DOUT>
+int launch_fuse_wf(const float* T0, const float* T1, const float* T2, const float* bw, const float* yvec, const float* wb,
+                   const float* outv, const float* dOut, int64_t n, float* dWf, float* ws, hipStream_t s) {
+  int64_t groups = (n + 255) / 256;
+  if (groups > kWfGroups) groups = kWfGroups;
+  if (groups < 1) groups = 1;
+  int64_t per = (n + groups - 1) / groups;
+  per = (per + 3) / 4 * 4;
+  groups = (n + per - 1) / per;
+  tgcn_fuse_wf_kernel<D, DOUT><<<static_cast<unsigned>(9 * groups), kFuseThreads, 0, s>>>(T0, T1, T2, bw, yvec, wb, outv, dOut,
+                                                                                          n, per, ws);
+  TAGREC_LAUNCH_CHECK();
+  const int64_t elems = (static_cast<int64_t>(kBitC) * D + 6 * kVecC) * DOUT;
+  fuse_fold_kernel<<<static_cast<unsigned>((elems + 255) / 256), 256, 0, s>>>(ws, static_cast<int>(groups),
+                                                                            static_cast<int>(elems), dWf);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
@@ -553,7 +659,8 @@ extern "C" int tagrec_tgcn_fuse_fwd_f32(const float* T0, const float* T1, const 
 }
 
 extern "C" int64_t tagrec_tgcn_fuse_bwd_workspace(int Dout) {
-  return static_cast<int64_t>(kFuseBwdBlocks) * (3 * kBitC + 2 * 32 + Dout);
+  (void)Dout;
+  return static_cast<int64_t>(kFuseBwdBlocks) * (3 * kBitC + 2 * 32);
 }
 
 extern "C" int tagrec_tgcn_fuse_bwd_f32(const float* T0, const float* T1, const float* T2, int64_t n, int D, int Dout,
@@ -573,6 +680,24 @@ extern "C" int tagrec_tgcn_fuse_bwd_f32(const float* T0, const float* T1, const 
   if (n <= 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(DD, OO) launch_fuse_bwd<DD, OO>(T0, T1, T2, n, U, q, p, wb, w1, w2, w3, Wf, out, dOut, dT0, dT1, dT2, yvec, dfeat, dS, small, workspace, s)
+  TAGREC_FUSE_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int64_t tagrec_tgcn_fuse_wf_workspace(int D, int Dout) {
+  return static_cast<int64_t>(kWfGroups) * (static_cast<int64_t>(kBitC) * D + 6 * kVecC) * Dout;
+}
+
+extern "C" int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, const float* bw,
+                                       const float* yvec, const float* wb, const float* out, const float* dOut, int64_t n,
+                                       int D, int Dout, int C, int V, float* dWf, float* workspace,
+                                       int64_t workspace_floats, void* stream) {
+  TAGREC_REQUIRE(T0 && T1 && T2 && bw && yvec && wb && out && dOut && dWf && workspace, "tgcn_fuse_wf: null pointer");
+  if (C != kBitC || V != kVecC) return fail(TAGREC_E_UNSUPPORTED, "tgcn_fuse: built for num_bit_conv 32, num_vec_conv 8");
+  TAGREC_REQUIRE(workspace_floats >= tagrec_tgcn_fuse_wf_workspace(D, Dout), "tgcn_fuse_wf: workspace too small");
+  TAGREC_REQUIRE(n >= 1, "tgcn_fuse_wf: empty input");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(DD, OO) launch_fuse_wf<DD, OO>(T0, T1, T2, bw, yvec, wb, out, dOut, n, dWf, workspace, s)
   TAGREC_FUSE_DISPATCH(CALL);
 #undef CALL
 }

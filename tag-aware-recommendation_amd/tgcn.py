@@ -146,7 +146,7 @@ class _FusedDense(torch.autograd.Function):
         yvec = torch.empty(n, 6 * V, dtype=torch.float32, device=dev)
         dfeat = torch.empty(n, 6 * V, dtype=torch.float32, device=dev)
         dS = torch.empty(n, 3 * A, dtype=torch.float32, device=dev)
-        small = torch.empty(3 * C + 2 * A + Dout, dtype=torch.float32, device=dev)
+        small = torch.empty(3 * C + 2 * A, dtype=torch.float32, device=dev)
         ws_n = lib.tagrec_tgcn_fuse_bwd_workspace(Dout)
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
         _lib.check(_timed("fuse_bwd", lib.tagrec_tgcn_fuse_bwd_f32, _lib.ptr(t0), _lib.ptr(t1), _lib.ptr(t2), n, D, Dout, A, C,
@@ -154,7 +154,7 @@ class _FusedDense(torch.autograd.Function):
                           _lib.ptr(Wf), _lib.ptr(out), _lib.ptr(d_out), _lib.ptr(dts[0]), _lib.ptr(dts[1]), _lib.ptr(dts[2]),
                           _lib.ptr(yvec), _lib.ptr(dfeat), _lib.ptr(dS), _lib.ptr(small), _lib.ptr(ws), ws_n,
                           _lib.stream_ptr()), "tgcn_fuse_bwd")
-        dwb, dq, dp, dbf = small[:3 * C].reshape(C, 3), small[3 * C:3 * C + A], small[3 * C + A:3 * C + 2 * A], small[3 * C + 2 * A:]
+        dwb, dq, dp = small[:3 * C].reshape(C, 3), small[3 * C:3 * C + A], small[3 * C + A:3 * C + 2 * A]
         # weight gradients that are plain GEMMs over the node axis
         ts = (t0, t1, t2)
         dU = sum(ts[j].t() @ dS[:, j * A:(j + 1) * A] for j in range(3))
@@ -163,16 +163,14 @@ class _FusedDense(torch.autograd.Function):
         dw1 = sum(f1[:, :, h].t() @ e3[h] for h in range(3))
         dw2 = torch.stack([sum(f2[:, :, h].t() @ e3[h + a] for h in range(2)) for a in range(2)], dim=1).reshape(V, -1)
         dw3 = torch.stack([f3.t() @ e3[a] for a in range(3)], dim=1).reshape(V, -1)
-        # fusion weight: dWf = y^T g, y re-formed chunk by chunk (interim; a dedicated kernel replaces this)
-        g = d_out * (out > 0)
-        dWf = torch.zeros_like(Wf)
-        for lo in range(0, n, ctx.chunk_rows):
-            hi = min(lo + ctx.chunk_rows, n)
-            bit = e3[0][lo:hi, None, :] * wb[None, :, 0, None]
-            bit = torch.addcmul(bit, e3[1][lo:hi, None, :], wb[None, :, 1, None])
-            bit = torch.addcmul(bit, e3[2][lo:hi, None, :], wb[None, :, 2, None])
-            y = torch.cat([torch.relu_(bit).reshape(hi - lo, -1), yvec[lo:hi]], dim=1)
-            dWf.addmm_(y.t(), g[lo:hi])
+        # fusion weight: dWf = y^T g with y re-formed inside the kernel; dbf = column sums of g
+        dbf = (d_out * (out > 0)).sum(0)
+        dWf = torch.empty_like(Wf)
+        wf_n = lib.tagrec_tgcn_fuse_wf_workspace(D, Dout)
+        wf_ws = torch.empty(wf_n, dtype=torch.float32, device=dev)
+        _lib.check(_timed("fuse_wf", lib.tagrec_tgcn_fuse_wf_f32, _lib.ptr(t0), _lib.ptr(t1), _lib.ptr(t2), _lib.ptr(bw),
+                          _lib.ptr(yvec), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(d_out), n, D, Dout, C, V, _lib.ptr(dWf),
+                          _lib.ptr(wf_ws), wf_n, _lib.stream_ptr()), "tgcn_fuse_wf")
         return (*dts, dU, dq, dp, dwb, dw1, dw2, dw3, dWf, dbf, None)
 
 

@@ -153,16 +153,25 @@ def test_fused_dense_block_vs_operator_form(D, Dout, n):
            torch.randn(V, 1, 1, D) * 0.2, torch.randn(V, 1, 2, D) * 0.2, torch.randn(V, 1, 3, D) * 0.2,
            torch.randn(C * D + 6 * V, Dout) * 0.05, torch.randn(1, Dout) * 0.1]
     up = torch.randn(n, Dout)
+    # ReLU is not differentiable at 0: a pre-activation within rounding distance of 0 (|x| ~ 1e-8 happens among
+    # the ~1e6 bit-level pre-activations) gets gradient 0 or 1 depending on the last bit, a finite difference no
+    # tolerance covers.  Such nodes get a zero upstream gradient so they do not take part in the comparison.
+    with torch.no_grad():
+        st64 = torch.stack([t.double() for t in ts], 1)
+        P64 = [x.double() for x in prm]
+        S64 = st64 @ P64[0] + P64[1]
+        e64 = torch.softmax(torch.relu(S64) @ P64[2].t(), dim=1) * st64
+        bit64 = torch.einsum("cj,njd->ncd", P64[3][:, 0, :, 0], e64)
+        amb = (bit64.abs().amin(dim=(1, 2)) < 1e-6) | (S64.abs().amin(dim=(1, 2)) < 1e-6)
+        up[amb] = 0.0
     rt = [t.double().requires_grad_() for t in ts]
-    rp = [x.double().requires_grad_() for x in prm]
-    want = TG._dense_block(torch.stack(rt, dim=1), *rp)
-    (want * up.double()).sum().backward()
     gt = [t.to(DEV).requires_grad_() for t in ts]
     gp = [x.to(DEV).requires_grad_() for x in prm]
     U, q, p, wb, w1, w2, w3, Wf, bf = gp
     got = TG._FusedDense.apply(gt[0], gt[1], gt[2], U, q.reshape(-1), p.reshape(-1), wb.reshape(C, 3), w1.reshape(V, -1),
                                w2.reshape(V, -1), w3.reshape(V, -1), Wf, bf.reshape(-1), 50)
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().float().numpy(), rtol=1e-4, atol=2e-5)
+    assert int(amb.sum()) < n // 20
     (got * up.to(DEV)).sum().backward()
     scale = max(float(x.grad.abs().max()) for x in rt + rp)
     for name, a, b in [(f"t{k}", gt[k], rt[k]) for k in range(3)] + [(f"p{k}", gp[k], rp[k]) for k in range(len(prm))]:
