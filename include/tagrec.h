@@ -140,9 +140,12 @@ int tagrec_ngcf_wgrad_f32(const float* N, const float* X, const float* dP1, cons
  * WT = cat(0, ew) W1[D:]  [n_wt, A] (row 0 = pad).  idx / widx: int32 [n, k], neighbour id + 1 and weight
  * index, 0 = pad (a zero row that still takes part in the softmax, as in the reference).
  *   fwd: attn[n,k] = softmax_k( relu(P[v] + WT[widx] + Q[idx-1]) . v );  out[v] = sum_k attn * Ej[idx-1]
- *   bwd: from dOut [n, D]: dP [n, A] (written), dQ [m, A] and dEj [m, D] (float-atomic scatter-add into
- *        caller-zeroed buffers), dWT [n_wt, A] and dv [A] (written; deterministic fold of per-block partials;
- *        workspace of tagrec_tgcn_attn_workspace(n_wt, A) floats).
+ *   bwd: from dOut [n, D]: dP [n, A] (written), dWT [n_wt, A] and dv [A] (written; deterministic fold of
+ *        per-block partials; workspace of tagrec_tgcn_attn_workspace(n_wt, A) floats), and EITHER
+ *        dh = NULL: dQ [m, A] and dEj [m, D] by float-atomic scatter-add into caller-zeroed buffers, OR
+ *        dh [n, k, A] (written): the per-(node, neighbour) pre-activation gradients; the caller then forms
+ *        dQ = S dh and dEj = G dOut as pull products over the inverted neighbour table with tagrec_spmm_f32
+ *        (S: unit values, columns = flat (node, slot) positions; G: values = attn, columns = source nodes).
  * D in {16,32,64,128,256}, A in {4,8,16,32,64}, k <= 64. */
 int64_t tagrec_tgcn_attn_workspace(int n_wt, int A);
 int tagrec_tgcn_attn_fwd_f32(const float* P, const float* Q, const float* WT, const float* v, const float* Ej,
@@ -151,7 +154,7 @@ int tagrec_tgcn_attn_fwd_f32(const float* P, const float* Q, const float* WT, co
 int tagrec_tgcn_attn_bwd_f32(const float* P, const float* Q, const float* WT, const float* v, const float* Ej,
                              const int32_t* idx, const int32_t* widx, const float* attn, const float* dOut,
                              int64_t n, int k, int D, int A, int n_wt, float* dP, float* dQ, float* dEj,
-                             float* dWT, float* dv, float* workspace, int64_t workspace_floats, void* stream);
+                             float* dh, float* dWT, float* dv, float* workspace, int64_t workspace_floats, void* stream);
 
 /* ---- TGCN type-level attention + bit/vector convolutions + fusion layer, fused (tgcn.py:78-106) ------------
  * One node type per call.  T0/T1/T2 [n, D]: the (user-side, item-side, tag-side) vectors of each node, in

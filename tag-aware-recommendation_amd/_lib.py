@@ -48,7 +48,7 @@ _SIGNATURES = {
                               c_void_p, c_int64, c_void_p],
     "tagrec_tgcn_attn_workspace": [c_int, c_int],
     "tagrec_tgcn_attn_fwd_f32": [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "tagrec_tgcn_attn_bwd_f32": [c_void_p] * 9 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_int64, c_void_p],
+    "tagrec_tgcn_attn_bwd_f32": [c_void_p] * 9 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [c_int64, c_void_p],
     "tagrec_tgcn_fuse_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 12,
     "tagrec_tgcn_fuse_bwd_workspace": [c_int],
     "tagrec_tgcn_fuse_bwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 18

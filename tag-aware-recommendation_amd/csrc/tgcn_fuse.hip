@@ -550,27 +550,42 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
     for (int i = 0; i < IB; ++i)
 #pragma unroll
       for (int o = 0; o < OB; ++o) acc[i][o] = zero4();
-    for (int64_t node0 = lo; node0 < hi; node0 += 4) {
+    // software pipeline: the raw operands of step s+1 are in flight while step s runs its IB x OB MFMAs
+    // (one wave per SIMD here -- the accumulator tile fills the register file -- so nothing else hides the latency)
+    struct Raw { float t0[IB], t1[IB], t2[IB], go[OB], ov[OB], b0, b1, b2; };
+    auto fetch = [&](int64_t node0, Raw& rw) {
       const int64_t node = node0 + q;
       const bool ok = node < hi;
-      float y[IB], g[OB];
-      const float b0 = ok ? bw[node * 3] : 0.f, b1 = ok ? bw[node * 3 + 1] : 0.f, b2 = ok ? bw[node * 3 + 2] : 0.f;
+      rw.b0 = ok ? bw[node * 3] : 0.f; rw.b1 = ok ? bw[node * 3 + 1] : 0.f; rw.b2 = ok ? bw[node * 3 + 2] : 0.f;
 #pragma unroll
       for (int i = 0; i < IB; ++i) {
         const int64_t off = node * D + i * 16 + m;
-        // same operation order as the forward kernel, so the ReLU mask is the forward's
-        const float e0 = ok ? T0[off] * b0 : 0.f, e1 = ok ? T1[off] * b1 : 0.f, e2 = ok ? T2[off] * b2 : 0.f;
-        y[i] = fmaxf(fmaf(c0, e0, fmaf(c1, e1, c2 * e2)), 0.f);
+        rw.t0[i] = ok ? T0[off] : 0.f; rw.t1[i] = ok ? T1[off] : 0.f; rw.t2[i] = ok ? T2[off] : 0.f;
       }
 #pragma unroll
       for (int o = 0; o < OB; ++o) {
         const int64_t off = node * DOUT + o * 16 + m;
-        g[o] = (ok && outv[off] > 0.f) ? dOut[off] : 0.f;
+        rw.go[o] = ok ? dOut[off] : 0.f; rw.ov[o] = ok ? outv[off] : 0.f;
       }
+    };
+    Raw cur, nxt;
+    fetch(lo, cur);
+    for (int64_t node0 = lo; node0 < hi; node0 += 4) {
+      fetch(node0 + 4, nxt);                       // rows past `hi` come back as zeros
+      float y[IB], g[OB];
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        // same operation order as the forward kernel, so the ReLU mask is the forward's
+        const float e0 = cur.t0[i] * cur.b0, e1 = cur.t1[i] * cur.b1, e2 = cur.t2[i] * cur.b2;
+        y[i] = fmaxf(fmaf(c0, e0, fmaf(c1, e1, c2 * e2)), 0.f);
+      }
+#pragma unroll
+      for (int o = 0; o < OB; ++o) g[o] = cur.ov[o] > 0.f ? cur.go[o] : 0.f;
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int o = 0; o < OB; ++o) acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[i], g[o], acc[i][o], 0, 0, 0);
+      cur = nxt;
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i)

@@ -27,13 +27,37 @@ from torch.utils.checkpoint import checkpoint
 
 from . import _lib, help as H
 from .config import CFG as _GLOBAL_CFG
+from .graph import Graph
+
+
+class InverseTable:
+    """A relation's neighbour table inverted once at start-up: for every destination row, the
+    (source node, slot) pairs that point at it, as two CSR graphs over the same row pointer --
+    S (unit values, columns = flat (node, slot) positions) and G (values = the step's attention weights,
+    columns = source nodes).  The attention backward then PULLS dQ = S dh and dEj = G dOut with the SpMM
+    kernel instead of scattering with float atomics."""
+
+    def __init__(self, idx, n_dst):
+        n, k = idx.shape
+        flat = idx.flatten().long()
+        pos = torch.nonzero(flat > 0).flatten()
+        dest = flat[pos] - 1
+        order = torch.argsort(dest, stable=True)
+        self.perm = pos[order].contiguous()
+        rowptr = torch.zeros(n_dst + 1, dtype=torch.int64, device=idx.device)
+        torch.cumsum(torch.bincount(dest, minlength=n_dst), 0, out=rowptr[1:])
+        ones = torch.ones(self.perm.numel(), dtype=torch.float32, device=idx.device)
+        self.S = Graph(rowptr, self.perm.to(torch.int32), ones, (n_dst, n * k))
+        self.G = Graph(rowptr, torch.div(self.perm, k, rounding_mode="floor").to(torch.int32), torch.zeros_like(ones),
+                       (n_dst, n))
 
 
 class _NbrAttention(torch.autograd.Function):
     """(P, Q, WT, v, Ej) + static index tables -> attended neighbour embedding [n, D]."""
 
     @staticmethod
-    def forward(ctx, P, Q, WT, v, Ej, idx, widx):
+    def forward(ctx, P, Q, WT, v, Ej, idx, widx, inv=None):
+        ctx.inv = inv
         P, Q, WT, v, Ej = (t.contiguous() for t in (P, Q, WT, v, Ej))
         n, A = P.shape
         k, D = idx.shape[1], Ej.shape[1]
@@ -52,19 +76,29 @@ class _NbrAttention(torch.autograd.Function):
         k, D, n_wt = idx.shape[1], Ej.shape[1], WT.shape[0]
         lib = _lib.load()
         dP = torch.empty_like(P)
-        dQ, dEj = torch.zeros_like(Q), torch.zeros_like(Ej)
         dWT, dv = torch.empty_like(WT), torch.empty_like(v)
         ws_n = lib.tagrec_tgcn_attn_workspace(n_wt, A)
         ws = torch.empty(ws_n, dtype=torch.float32, device=P.device)
+        d_out = d_out.contiguous()
+        inv = ctx.inv
+        if inv is None:                  # scatter form: float atomics into zeroed buffers
+            dQ, dEj, dh = torch.zeros_like(Q), torch.zeros_like(Ej), None
+        else:                            # pull form: write dh, finish with two SpMMs over the inverted table
+            dQ = dEj = None
+            dh = torch.empty(n * k, A, dtype=torch.float32, device=P.device)
         _lib.check(_timed("attn_bwd", lib.tagrec_tgcn_attn_bwd_f32, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v),
-                          _lib.ptr(Ej), _lib.ptr(idx), _lib.ptr(widx), _lib.ptr(attn), _lib.ptr(d_out.contiguous()),
-                          n, k, D, A, n_wt, _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dEj), _lib.ptr(dWT),
+                          _lib.ptr(Ej), _lib.ptr(idx), _lib.ptr(widx), _lib.ptr(attn), _lib.ptr(d_out),
+                          n, k, D, A, n_wt, _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dEj), _lib.ptr(dh), _lib.ptr(dWT),
                           _lib.ptr(dv), _lib.ptr(ws), ws_n, _lib.stream_ptr()), "tgcn_attn_bwd")
-        return dP, dQ, dWT, dv, dEj, None, None
+        if inv is not None:
+            torch.index_select(attn.reshape(-1), 0, inv.perm, out=inv.G.val)
+            dEj = inv.G.spmm(d_out)
+            dQ = inv.S.spmm(dh)
+        return dP, dQ, dWT, dv, dEj, None, None, None
 
 
-def neighbour_attention(P, Q, WT, v, Ej, idx, widx):
-    return _NbrAttention.apply(P, Q, WT, v, Ej, idx, widx)
+def neighbour_attention(P, Q, WT, v, Ej, idx, widx, inv=None):
+    return _NbrAttention.apply(P, Q, WT, v, Ej, idx, widx, inv)
 
 
 class _Att(nn.Module):
@@ -213,22 +247,22 @@ class _Layer(nn.Module):
                 outs.append(_dense_block(part, *args))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
-    def forward(self, eu, ei, et, ewp, nbr, chunk_rows, use_checkpoint, fused=True):
+    def forward(self, eu, ei, et, ewp, nbr, chunk_rows, use_checkpoint, fused=True, inv=None):
         D = self.in_features
+        inv = inv if inv is not None else [None] * 6
         emb = {"user": eu, "item": ei, "tag": et}
         # per neighbour type: Q = e W2 and the weight look-up table, shared by the two relations it serves
         Q = {t: emb[t] @ self.atten1[t].W_2 for t in emb}
         WT = {t: ewp @ self.atten1[t].W_1[D:] for t in emb}
 
-        def att(src, nb, pair):
+        def att(src, nb, r):
             a = self.atten1[nb]
             P = emb[src] @ a.W_1[:D] + a.b
-            return neighbour_attention(P, Q[nb], WT[nb], a.v.reshape(-1), emb[nb], pair[0], pair[1])
+            return neighbour_attention(P, Q[nb], WT[nb], a.v.reshape(-1), emb[nb], nbr[r][0], nbr[r][1], inv[r])
 
-        u_i, u_t, i_u, i_t, t_u, t_i = nbr
-        eu_i, eu_t = att("user", "item", u_i), att("user", "tag", u_t)
-        ei_u, ei_t = att("item", "user", i_u), att("item", "tag", i_t)
-        et_u, et_i = att("tag", "user", t_u), att("tag", "item", t_i)
+        eu_i, eu_t = att("user", "item", 0), att("user", "tag", 1)
+        ei_u, ei_t = att("item", "user", 2), att("item", "tag", 3)
+        et_u, et_i = att("tag", "user", 4), att("tag", "item", 5)
         outs = []
         for trip in ((eu, eu_i, eu_t), (ei_u, ei, ei_t), (et_u, et_i, et)):
             outs.append(self.dense(trip, chunk_rows, use_checkpoint, fused))
@@ -354,6 +388,8 @@ class TGCN(nn.Module):
                 return t[:, :self.neighbor_k].to(self.device, torch.int32).contiguous()
             return torch.as_tensor(np.asarray(t)[:, :self.neighbor_k].astype(np.int32)).contiguous().to(self.device)
         self.nbr = [tuple(up(t) for t in pair) for pair in neighbors]
+        n_dst = [self.num_item, self.num_tag, self.num_user, self.num_tag, self.num_user, self.num_item]
+        self.inv = [InverseTable(self.nbr[r][0], n_dst[r]) for r in range(6)] if self.pull_backward else None
         self._eval_cache = None
 
     def _config(self, config):
@@ -375,6 +411,7 @@ class TGCN(nn.Module):
         self.chunk_rows = config.get("tgcn_chunk_rows", 65536)
         self.use_checkpoint = config.get("tgcn_checkpoint", True)
         self.fused_dense = config.get("tgcn_fused_dense", True)
+        self.pull_backward = config.get("tgcn_pull_backward", True)
 
     def train(self, mode=True):
         self._eval_cache = None
@@ -385,7 +422,7 @@ class TGCN(nn.Module):
         ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])          # index 0 = pad (tgcn.py:21-24)
         cu, ci, ct = [eu], [ei], [et]
         for i, layer in enumerate(self.layer.values()):
-            eu, ei, et = layer(eu, ei, et, ewp, self.nbr, self.chunk_rows, self.use_checkpoint, self.fused_dense)
+            eu, ei, et = layer(eu, ei, et, ewp, self.nbr, self.chunk_rows, self.use_checkpoint, self.fused_dense, self.inv)
             p = self.message_drop_list[i]
             if self.training and p > 0:
                 eu, ei, et = (torch.nn.functional.dropout(t, p=p, training=True) for t in (eu, ei, et))

@@ -93,8 +93,9 @@ def test_transtag_phase_golden(golden):
         _close(m.embed[k].grad.cpu().numpy(), fx[f"tt_grad.embed.{k}"], k, rtol=1e-4)
 
 
+@pytest.mark.parametrize("pull", [False, True])
 @pytest.mark.parametrize("D,k,A", [(128, 25, 32), (64, 25, 32), (16, 5, 32), (32, 64, 16), (256, 3, 64)])
-def test_attention_kernels_vs_oracle(D, k, A):
+def test_attention_kernels_vs_oracle(D, k, A, pull):
     """`Attention1` through the HIP kernels vs the oracle's direct restatement, C4-shaped rows (D=128, k=25)."""
     torch.manual_seed(D + k)
     n, m, nw, dw = 300, 200, 7, 10
@@ -113,8 +114,10 @@ def test_attention_kernels_vs_oracle(D, k, A):
     gv, gj, gw = (t.clone().to(DEV).requires_grad_() for t in (ev, ej, ew))
     ewp = torch.cat([gw.new_zeros(1, dw), gw])
     P = gv @ g["W_1"][:D] + g["b"]
+    idx_d = idx.to(DEV, torch.int32).contiguous()
+    inv = TG.InverseTable(idx_d, m) if pull else None        # pull form: dQ / dEj through the inverted table + SpMM
     got = TG.neighbour_attention(P, gj @ g["W_2"], ewp @ g["W_1"][D:], g["v"].reshape(-1), gj,
-                                 idx.to(DEV, torch.int32).contiguous(), widx.to(DEV, torch.int32).contiguous())
+                                 idx_d, widx.to(DEV, torch.int32).contiguous(), inv)
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-6)
     (got * up.to(DEV)).sum().backward()
     for name, a, b in (("ev", gv, rv), ("ej", gj, rj), ("ew", gw, rw)):
@@ -165,6 +168,9 @@ def test_fused_dense_block_vs_operator_form(D, Dout, n):
         amb = (bit64.abs().amin(dim=(1, 2)) < 1e-6) | (S64.abs().amin(dim=(1, 2)) < 1e-6)
         up[amb] = 0.0
     rt = [t.double().requires_grad_() for t in ts]
+    rp = [x.double().requires_grad_() for x in prm]
+    want = TG._dense_block(torch.stack(rt, dim=1), *rp)
+    (want * up.double()).sum().backward()
     gt = [t.to(DEV).requires_grad_() for t in ts]
     gp = [x.to(DEV).requires_grad_() for x in prm]
     U, q, p, wb, w1, w2, w3, Wf, bf = gp
