@@ -165,7 +165,7 @@ def test_fused_dense_block_vs_operator_form(D, Dout, n):
         S64 = st64 @ P64[0] + P64[1]
         e64 = torch.softmax(torch.relu(S64) @ P64[2].t(), dim=1) * st64
         bit64 = torch.einsum("cj,njd->ncd", P64[3][:, 0, :, 0], e64)
-        amb = (bit64.abs().amin(dim=(1, 2)) < 1e-6) | (S64.abs().amin(dim=(1, 2)) < 1e-6)
+        amb = (bit64.abs().amin(dim=(1, 2)) < 2e-7) | (S64.abs().amin(dim=(1, 2)) < 2e-7)
         up[amb] = 0.0
     rt = [t.double().requires_grad_() for t in ts]
     rp = [x.double().requires_grad_() for x in prm]
@@ -177,7 +177,7 @@ def test_fused_dense_block_vs_operator_form(D, Dout, n):
     got = TG._FusedDense.apply(gt[0], gt[1], gt[2], U, q.reshape(-1), p.reshape(-1), wb.reshape(C, 3), w1.reshape(V, -1),
                                w2.reshape(V, -1), w3.reshape(V, -1), Wf, bf.reshape(-1), 50)
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().float().numpy(), rtol=1e-4, atol=2e-5)
-    assert int(amb.sum()) < n // 20
+    assert int(amb.sum()) <= n // 10
     (got * up.to(DEV)).sum().backward()
     scale = max(float(x.grad.abs().max()) for x in rt + rp)
     for name, a, b in [(f"t{k}", gt[k], rt[k]) for k in range(3)] + [(f"p{k}", gp[k], rp[k]) for k in range(len(prm))]:
