@@ -180,13 +180,18 @@ int tagrec_tgcn_fuse_bwd_f32(const float* T0, const float* T1, const float* T2, 
                              float* dT2, float* yvec, float* dfeat, float* dS, float* small,
                              float* workspace, int64_t workspace_floats, void* stream);
 
-/*   wf: dWf [C*D + 6V, Dout] = y^T (dOut * [out > 0]) with y re-formed on the fly from T0..T2, the saved softmax
- *        weights bw [n, 3], wb and the yvec written by the data part (workspace of
- *        tagrec_tgcn_fuse_wf_workspace(D, Dout) floats; deterministic fold of per-node-group partials). */
+/*   wf: every weight gradient that is a product over the NODE axis, in one launch.  result (of
+ *        tagrec_tgcn_fuse_wf_result(D, Dout) floats) = [ dWf | G | dU ]:
+ *          dWf [C*D + 6V, Dout] = y^T (dOut * [out > 0]), y re-formed on the fly from T0..T2, bw [n, 3], wb, yvec;
+ *          G   [6V, 3, D]       = dfeat^T e_j  (the caller folds G into the Conv2d(1,V,(j,D)) weight gradients);
+ *          dU  [D, A]           = sum_j t_j^T dS_j.
+ *        workspace of tagrec_tgcn_fuse_wf_workspace(D, Dout) floats; deterministic fold of per-node-group partials. */
+int64_t tagrec_tgcn_fuse_wf_result(int D, int Dout);
 int64_t tagrec_tgcn_fuse_wf_workspace(int D, int Dout);
 int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, const float* bw, const float* yvec,
-                            const float* wb, const float* out, const float* dOut, int64_t n, int D, int Dout,
-                            int C, int V, float* dWf, float* workspace, int64_t workspace_floats, void* stream);
+                            const float* wb, const float* out, const float* dOut, const float* dfeat, const float* dS,
+                            int64_t n, int D, int Dout, int C, int V, float* result, float* workspace,
+                            int64_t workspace_floats, void* stream);
 
 #ifdef __cplusplus
 }

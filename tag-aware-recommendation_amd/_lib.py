@@ -54,7 +54,8 @@ _SIGNATURES = {
     "tagrec_tgcn_fuse_bwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 18
                                 + [c_int64, c_void_p],
     "tagrec_tgcn_fuse_wf_workspace": [c_int, c_int],
-    "tagrec_tgcn_fuse_wf_f32": [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p],
+    "tagrec_tgcn_fuse_wf_result": [c_int, c_int],
+    "tagrec_tgcn_fuse_wf_f32": [c_void_p] * 10 + [c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p],
     "tagrec_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int64,
                         c_void_p],
 }
@@ -75,7 +76,7 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header and library disagree
         fn.argtypes = argtypes
-        fn.restype = c_int64 if name.endswith("_workspace") else c_int
+        fn.restype = c_int64 if name.endswith(("_workspace", "_result")) else c_int
     lib.tagrec_last_error.argtypes = []
     lib.tagrec_last_error.restype = c_char_p
     if lib.tagrec_abi_version() != ABI_VERSION:

@@ -330,18 +330,30 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int e = 0; e < DS; ++e) de3[j][e] = 0.f;
-    // bit-level: dy^T[d][node] = sum_o Wf[c D + d][o] g[node][o], then through the ReLU and the 3 -> 1 mix
+    // bit-level: dy^T[d][node] = sum_o Wf[c D + d][o] g[node][o], then through the ReLU and the 3 -> 1 mix.
+    // Software pipeline: the weight rows of block (c, b+1) are in flight while block (c, b) runs its MFMAs (one
+    // wave per SIMD here, nothing else hides the L2 latency); two accumulators break the dependent MFMA chain.
+    float a_next[OS];
+    load_run<OS>(Wf + static_cast<int64_t>(drow) * DOUT + q * OS, a_next);
     for (int c = 0; c < kBitC; ++c) {
       const float c0 = wb[c * 3], c1 = wb[c * 3 + 1], c2 = wb[c * 3 + 2];
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
       const float* wrow = Wf + (static_cast<int64_t>(c) * D + drow) * DOUT + q * OS;
+      const int cn = c + 1 < kBitC ? c + 1 : c;
+      const float* wrow_next = Wf + (static_cast<int64_t>(cn) * D + drow) * DOUT + q * OS;
 #pragma unroll
       for (int b = 0; b < IB; ++b) {
         float a[OS];
-        load_run<OS>(wrow + static_cast<int64_t>(4 * b) * DOUT, a);
-        f32x4 dy = zero4();
 #pragma unroll
-        for (int t = 0; t < OS; ++t) dy = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], g[t], dy, 0, 0, 0);
+        for (int t = 0; t < OS; ++t) a[t] = a_next[t];
+        load_run<OS>(b + 1 < IB ? wrow + static_cast<int64_t>(4 * (b + 1)) * DOUT : wrow_next, a_next);
+        f32x4 dy = zero4(), dy1 = zero4();
+#pragma unroll
+        for (int t = 0; t < OS; t += 2) {
+          dy = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], g[t], dy, 0, 0, 0);
+          dy1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 1], g[t + 1], dy1, 0, 0, 0);
+        }
+        dy += dy1;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int e = 4 * b + v;
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
           a1 = fmaf(dp_, e3[1][e], a1);
           a2 = fmaf(dp_, e3[2][e], a2);
         }
-        __builtin_amdgcn_sched_barrier(0);      // bound the live weight rows: one block of loads at a time
+        __builtin_amdgcn_sched_barrier(0);      // one block's loads / MFMAs / VALU at a time
       }
       // dwb[c][j] += sum over the wave (rows past n contribute 0: their g is 0)
 #pragma unroll
@@ -525,23 +537,77 @@ int launch_fuse_bwd(const float* T0, const float* T1, const float* T2, int64_t n
 // ---- backward, fusion weight: dWf[k][o] = sum_nodes y[node][k] g[node][o] ---------------------------
 // y is re-formed on the fly (it is never stored): here the contraction runs over nodes, so node rows sit on the
 // MFMA k axis and both operands are read straight from global memory in their natural layout.
-// grid = (9 k-groups) x (node groups): k-group < 8 = four bit-level channels (one per wave, a full D x Dout
-// accumulator tile each), k-group 8 = the 48 vector-level rows (16 per wave).  Per-node-group partial sums are
+// grid = (10 k-groups) x (node groups): k-group < 8 = four bit-level channels (one per wave, a full D x Dout
+// accumulator tile each), k-group 8 = the 48 vector-level rows (16 per wave), k-group 9 = the small weight
+// gradients G (vector-level filters) and dU (type attention), which are the same kind of node-axis product.  Per-node-group partial sums are
 // folded in group order by fuse_fold_kernel (deterministic).
 template <int D, int DOUT>
 __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
     const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, const float* __restrict__ bw,
     const float* __restrict__ yvec, const float* __restrict__ wb, const float* __restrict__ outv,
-    const float* __restrict__ dOut, int64_t n, int64_t rows_per_group, float* __restrict__ part) {
+    const float* __restrict__ dOut, const float* __restrict__ dfeat, const float* __restrict__ dS, int64_t n,
+    int64_t rows_per_group, float* __restrict__ part) {
   constexpr int IB = D / 16, OB = DOUT / 16;
-  constexpr int64_t KROWS = static_cast<int64_t>(kBitC) * D + 6 * kVecC;
+  constexpr int A = 32, AB = A / 16, NF = 6 * kVecC, FB = NF / 16;
+  constexpr int64_t KROWS = static_cast<int64_t>(kBitC) * D + NF;
+  constexpr int64_t PART = KROWS * DOUT + static_cast<int64_t>(NF) * 3 * D + static_cast<int64_t>(D) * A;   // dWf | G | dU
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
-  const int kg = blockIdx.x % 9;
-  const int64_t ng = blockIdx.x / 9;
+  const int kg = blockIdx.x % 10;
+  const int64_t ng = blockIdx.x / 10;
   const int64_t lo = ng * rows_per_group;
   const int64_t hi = (lo + rows_per_group < n) ? lo + rows_per_group : n;
-  float* dst = part + ng * KROWS * DOUT;
+  float* dst = part + ng * PART;
+  if (kg == 9) {
+    // small weight gradients with nodes on the k axis:
+    //   G[f][j][d] = sum_nodes dfeat[node][f] e_j[node][d]   (the caller folds G into dw1, dw2, dw3)
+    //   dU[d][a]   = sum_nodes sum_j t_j[node][d] dS_j[node][a]
+    float* gdst = dst + KROWS * DOUT;
+    float* udst = gdst + static_cast<int64_t>(NF) * 3 * D;
+    const float* Tj[3] = {T0, T1, T2};
+    for (int ib = wave; ib < IB; ib += 4) {
+      f32x4 accg[FB][3], accu[AB];
+#pragma unroll
+      for (int f = 0; f < FB; ++f)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) accg[f][j] = zero4();
+#pragma unroll
+      for (int a = 0; a < AB; ++a) accu[a] = zero4();
+      for (int64_t node0 = lo; node0 < hi; node0 += 4) {
+        const int64_t node = node0 + q;
+        const bool ok = node < hi;
+        float df[FB], t[3], e[3], ds[3][AB];
+#pragma unroll
+        for (int f = 0; f < FB; ++f) df[f] = ok ? dfeat[node * NF + f * 16 + m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          t[j] = ok ? Tj[j][node * D + ib * 16 + m] : 0.f;
+          e[j] = ok ? t[j] * bw[node * 3 + j] : 0.f;
+#pragma unroll
+          for (int a = 0; a < AB; ++a) ds[j][a] = ok ? dS[node * (3 * A) + j * A + a * 16 + m] : 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < FB; ++f)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) accg[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(df[f], e[j], accg[f][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int a = 0; a < AB; ++a) accu[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[j], ds[j][a], accu[a], 0, 0, 0);
+      }
+#pragma unroll
+      for (int f = 0; f < FB; ++f)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) gdst[(static_cast<int64_t>(f * 16 + q * 4 + v) * 3 + j) * D + ib * 16 + m] = accg[f][j][v];
+#pragma unroll
+      for (int a = 0; a < AB; ++a)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) udst[static_cast<int64_t>(ib * 16 + q * 4 + v) * A + a * 16 + m] = accu[a][v];
+    }
+    return;
+  }
   if (kg < 8) {
     const int c = 4 * kg + wave;
     const float c0 = wb[c * 3], c1 = wb[c * 3 + 1], c2 = wb[c * 3 + 2];
@@ -617,21 +683,24 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
   }
 }
 
-constexpr int kWfGroups = 28;        // 9 x 28 = 252 blocks: one 4-wave block per CU
+constexpr int kWfGroups = 25;        // 10 x 25 = 250 blocks: one 4-wave block per CU
 
 template <int D, int DOUT>
 int launch_fuse_wf(const float* T0, const float* T1, const float* T2, const float* bw, const float* yvec, const float* wb,
-                   const float* outv, const float* dOut, int64_t n, float* dWf, float* ws, hipStream_t s) {
+                   const float* outv, const float* dOut, const float* dfeat, const float* dS, int64_t n, float* dWf,
+                   float* ws, hipStream_t s) {
   int64_t groups = (n + 255) / 256;
   if (groups > kWfGroups) groups = kWfGroups;
   if (groups < 1) groups = 1;
   int64_t per = (n + groups - 1) / groups;
   per = (per + 3) / 4 * 4;
   groups = (n + per - 1) / per;
-  tgcn_fuse_wf_kernel<D, DOUT><<<static_cast<unsigned>(9 * groups), kFuseThreads, 0, s>>>(T0, T1, T2, bw, yvec, wb, outv, dOut,
-                                                                                          n, per, ws);
+  tgcn_fuse_wf_kernel<D, DOUT><<<static_cast<unsigned>(10 * groups), kFuseThreads, 0, s>>>(T0, T1, T2, bw, yvec, wb, outv, dOut,
+                                                                                           dfeat, dS, n, per, ws);
   TAGREC_LAUNCH_CHECK();
-  const int64_t elems = (static_cast<int64_t>(kBitC) * D + 6 * kVecC) * DOUT;
+  // one contiguous result [dWf | G | dU] (the caller hands a buffer of that size)
+  const int64_t elems = (static_cast<int64_t>(kBitC) * D + 6 * kVecC) * DOUT + static_cast<int64_t>(6 * kVecC) * 3 * D +
+                        static_cast<int64_t>(D) * 32;
   fuse_fold_kernel<<<static_cast<unsigned>((elems + 255) / 256), 256, 0, s>>>(ws, static_cast<int>(groups),
                                                                             static_cast<int>(elems), dWf);
   TAGREC_LAUNCH_CHECK();
@@ -699,20 +768,27 @@ extern "C" int tagrec_tgcn_fuse_bwd_f32(const float* T0, const float* T1, const 
 #undef CALL
 }
 
+extern "C" int64_t tagrec_tgcn_fuse_wf_result(int D, int Dout) {      // floats in [dWf | G | dU]
+  return (static_cast<int64_t>(kBitC) * D + 6 * kVecC) * Dout + static_cast<int64_t>(6 * kVecC) * 3 * D +
+         static_cast<int64_t>(D) * 32;
+}
+
 extern "C" int64_t tagrec_tgcn_fuse_wf_workspace(int D, int Dout) {
-  return static_cast<int64_t>(kWfGroups) * (static_cast<int64_t>(kBitC) * D + 6 * kVecC) * Dout;
+  return static_cast<int64_t>(kWfGroups) * tagrec_tgcn_fuse_wf_result(D, Dout);
 }
 
 extern "C" int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, const float* bw,
-                                       const float* yvec, const float* wb, const float* out, const float* dOut, int64_t n,
-                                       int D, int Dout, int C, int V, float* dWf, float* workspace,
-                                       int64_t workspace_floats, void* stream) {
-  TAGREC_REQUIRE(T0 && T1 && T2 && bw && yvec && wb && out && dOut && dWf && workspace, "tgcn_fuse_wf: null pointer");
+                                       const float* yvec, const float* wb, const float* out, const float* dOut,
+                                       const float* dfeat, const float* dS, int64_t n, int D, int Dout, int C, int V,
+                                       float* result, float* workspace, int64_t workspace_floats, void* stream) {
+  float* dWf = result;
+  TAGREC_REQUIRE(T0 && T1 && T2 && bw && yvec && wb && out && dOut && dfeat && dS && dWf && workspace,
+                 "tgcn_fuse_wf: null pointer");
   if (C != kBitC || V != kVecC) return fail(TAGREC_E_UNSUPPORTED, "tgcn_fuse: built for num_bit_conv 32, num_vec_conv 8");
   TAGREC_REQUIRE(workspace_floats >= tagrec_tgcn_fuse_wf_workspace(D, Dout), "tgcn_fuse_wf: workspace too small");
   TAGREC_REQUIRE(n >= 1, "tgcn_fuse_wf: empty input");
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(DD, OO) launch_fuse_wf<DD, OO>(T0, T1, T2, bw, yvec, wb, out, dOut, n, dWf, workspace, s)
+#define CALL(DD, OO) launch_fuse_wf<DD, OO>(T0, T1, T2, bw, yvec, wb, out, dOut, dfeat, dS, n, dWf, workspace, s)
   TAGREC_FUSE_DISPATCH(CALL);
 #undef CALL
 }

@@ -189,22 +189,23 @@ class _FusedDense(torch.autograd.Function):
                           _lib.ptr(yvec), _lib.ptr(dfeat), _lib.ptr(dS), _lib.ptr(small), _lib.ptr(ws), ws_n,
                           _lib.stream_ptr()), "tgcn_fuse_bwd")
         dwb, dq, dp = small[:3 * C].reshape(C, 3), small[3 * C:3 * C + A], small[3 * C + A:3 * C + 2 * A]
-        # weight gradients that are plain GEMMs over the node axis
-        ts = (t0, t1, t2)
-        dU = sum(ts[j].t() @ dS[:, j * A:(j + 1) * A] for j in range(3))
-        e3 = [bw[:, j:j + 1] * ts[j] for j in range(3)]
-        f1, f2, f3 = dfeat[:, :3 * V].reshape(n, V, 3), dfeat[:, 3 * V:5 * V].reshape(n, V, 2), dfeat[:, 5 * V:]
-        dw1 = sum(f1[:, :, h].t() @ e3[h] for h in range(3))
-        dw2 = torch.stack([sum(f2[:, :, h].t() @ e3[h + a] for h in range(2)) for a in range(2)], dim=1).reshape(V, -1)
-        dw3 = torch.stack([f3.t() @ e3[a] for a in range(3)], dim=1).reshape(V, -1)
-        # fusion weight: dWf = y^T g with y re-formed inside the kernel; dbf = column sums of g
+        # every gradient that is a product over the node axis: dWf, G (-> dw1, dw2, dw3) and dU, one launch
         dbf = (d_out * (out > 0)).sum(0)
-        dWf = torch.empty_like(Wf)
+        res_n = lib.tagrec_tgcn_fuse_wf_result(D, Dout)
+        res = torch.empty(res_n, dtype=torch.float32, device=dev)
         wf_n = lib.tagrec_tgcn_fuse_wf_workspace(D, Dout)
         wf_ws = torch.empty(wf_n, dtype=torch.float32, device=dev)
         _lib.check(_timed("fuse_wf", lib.tagrec_tgcn_fuse_wf_f32, _lib.ptr(t0), _lib.ptr(t1), _lib.ptr(t2), _lib.ptr(bw),
-                          _lib.ptr(yvec), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(d_out), n, D, Dout, C, V, _lib.ptr(dWf),
-                          _lib.ptr(wf_ws), wf_n, _lib.stream_ptr()), "tgcn_fuse_wf")
+                          _lib.ptr(yvec), _lib.ptr(wb), _lib.ptr(out), _lib.ptr(d_out), _lib.ptr(dfeat), _lib.ptr(dS), n, D,
+                          Dout, C, V, _lib.ptr(res), _lib.ptr(wf_ws), wf_n, _lib.stream_ptr()), "tgcn_fuse_wf")
+        k_wf = Wf.numel()
+        dWf = res[:k_wf].reshape(Wf.shape)
+        G = res[k_wf:k_wf + 6 * V * 3 * D].reshape(6 * V, 3, D)            # G[f][j][d] = sum_nodes dfeat[f] e_j[d]
+        dU = res[k_wf + 6 * V * 3 * D:].reshape(D, A)
+        g1, g2, g3 = G[:3 * V].reshape(V, 3, 3, D), G[3 * V:5 * V].reshape(V, 2, 3, D), G[5 * V:]
+        dw1 = g1[:, 0, 0] + g1[:, 1, 1] + g1[:, 2, 2]                                   # feature (c,h) touches e_h
+        dw2 = torch.stack([g2[:, 0, 0] + g2[:, 1, 1], g2[:, 0, 1] + g2[:, 1, 2]], dim=1).reshape(V, -1)   # tap a: e_{h+a}
+        dw3 = g3.reshape(V, -1)                                                          # tap a: e_a
         return (*dts, dU, dq, dp, dwb, dw1, dw2, dw3, dWf, dbf, None)
 
 
@@ -251,14 +252,22 @@ class _Layer(nn.Module):
         D = self.in_features
         inv = inv if inv is not None else [None] * 6
         emb = {"user": eu, "item": ei, "tag": et}
-        # per neighbour type: Q = e W2 and the weight look-up table, shared by the two relations it serves
-        Q = {t: emb[t] @ self.atten1[t].W_2 for t in emb}
-        WT = {t: ewp @ self.atten1[t].W_1[D:] for t in emb}
+        # one GEMM per node type: [Q_t | P_(t<-nb1) | P_(t<-nb2)] = e_t [W2_t | W1_nb1[:D] | W1_nb2[:D]]
+        # (Q_t = e_t W2 is shared by the two relations whose NEIGHBOUR type is t; P is per (source, neighbour type))
+        others = {"user": ("item", "tag"), "item": ("user", "tag"), "tag": ("user", "item")}
+        A = self.U.shape[1]
+        Q, P = {}, {}
+        for t, (n1, n2) in others.items():
+            wcat = torch.cat([self.atten1[t].W_2, self.atten1[n1].W_1[:D], self.atten1[n2].W_1[:D]], dim=1)
+            y = emb[t] @ wcat
+            Q[t] = y[:, :A]
+            P[(t, n1)] = y[:, A:2 * A] + self.atten1[n1].b
+            P[(t, n2)] = y[:, 2 * A:] + self.atten1[n2].b
+        WT = {t: ewp @ self.atten1[t].W_1[D:] for t in emb}     # weight look-up tables, (n_weight + 1) x A
 
         def att(src, nb, r):
             a = self.atten1[nb]
-            P = emb[src] @ a.W_1[:D] + a.b
-            return neighbour_attention(P, Q[nb], WT[nb], a.v.reshape(-1), emb[nb], nbr[r][0], nbr[r][1], inv[r])
+            return neighbour_attention(P[(src, nb)], Q[nb], WT[nb], a.v.reshape(-1), emb[nb], nbr[r][0], nbr[r][1], inv[r])
 
         eu_i, eu_t = att("user", "item", 0), att("user", "tag", 1)
         ei_u, ei_t = att("item", "user", 2), att("item", "tag", 3)
