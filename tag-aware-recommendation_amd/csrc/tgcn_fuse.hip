@@ -565,46 +565,66 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
     float* gdst = dst + KROWS * DOUT;
     float* udst = gdst + static_cast<int64_t>(NF) * 3 * D;
     const float* Tj[3] = {T0, T1, T2};
-    for (int ib = wave; ib < IB; ib += 4) {
-      f32x4 accg[FB][3], accu[AB];
+    constexpr int IBW = (IB + 3) / 4;              // input-feature blocks per wave: ib = wave + 4 i
+    f32x4 accg[IBW][FB][3], accu[IBW][AB];
+#pragma unroll
+    for (int i = 0; i < IBW; ++i) {
 #pragma unroll
       for (int f = 0; f < FB; ++f)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) accg[f][j] = zero4();
+        for (int j = 0; j < 3; ++j) accg[i][f][j] = zero4();
 #pragma unroll
-      for (int a = 0; a < AB; ++a) accu[a] = zero4();
-      for (int64_t node0 = lo; node0 < hi; node0 += 4) {
-        const int64_t node = node0 + q;
-        const bool ok = node < hi;
-        float df[FB], t[3], e[3], ds[3][AB];
+      for (int a = 0; a < AB; ++a) accu[i][a] = zero4();
+    }
+    struct RawS { float df[FB], b[3], t[3][IBW], ds[3][AB]; };
+    auto fetch_s = [&](int64_t node0, RawS& rw) {
+      const int64_t node = node0 + q;
+      const bool ok = node < hi;
 #pragma unroll
-        for (int f = 0; f < FB; ++f) df[f] = ok ? dfeat[node * NF + f * 16 + m] : 0.f;
+      for (int f = 0; f < FB; ++f) rw.df[f] = ok ? dfeat[node * NF + f * 16 + m] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          t[j] = ok ? Tj[j][node * D + ib * 16 + m] : 0.f;
-          e[j] = ok ? t[j] * bw[node * 3 + j] : 0.f;
+      for (int j = 0; j < 3; ++j) {
+        rw.b[j] = ok ? bw[node * 3 + j] : 0.f;
 #pragma unroll
-          for (int a = 0; a < AB; ++a) ds[j][a] = ok ? dS[node * (3 * A) + j * A + a * 16 + m] : 0.f;
+        for (int i = 0; i < IBW; ++i) {
+          const int ib = wave + 4 * i;
+          rw.t[j][i] = (ok && ib < IB) ? Tj[j][node * D + ib * 16 + m] : 0.f;
         }
 #pragma unroll
-        for (int f = 0; f < FB; ++f)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) accg[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(df[f], e[j], accg[f][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int a = 0; a < AB; ++a) accu[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[j], ds[j][a], accu[a], 0, 0, 0);
+        for (int a = 0; a < AB; ++a) rw.ds[j][a] = ok ? dS[node * (3 * A) + j * A + a * 16 + m] : 0.f;
       }
+    };
+    RawS cur, nxt;
+    fetch_s(lo, cur);
+    for (int64_t node0 = lo; node0 < hi; node0 += 4) {
+      fetch_s(node0 + 4, nxt);
+#pragma unroll
+      for (int i = 0; i < IBW; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float e = cur.t[j][i] * cur.b[j];
+#pragma unroll
+          for (int f = 0; f < FB; ++f) accg[i][f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.df[f], e, accg[i][f][j], 0, 0, 0);
+#pragma unroll
+          for (int a = 0; a < AB; ++a) accu[i][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.t[j][i], cur.ds[j][a], accu[i][a], 0, 0, 0);
+        }
+      }
+      cur = nxt;
+    }
+#pragma unroll
+    for (int i = 0; i < IBW; ++i) {
+      const int ib = wave + 4 * i;
+      if (ib >= IB) continue;
 #pragma unroll
       for (int f = 0; f < FB; ++f)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) gdst[(static_cast<int64_t>(f * 16 + q * 4 + v) * 3 + j) * D + ib * 16 + m] = accg[f][j][v];
+          for (int v = 0; v < 4; ++v) gdst[(static_cast<int64_t>(f * 16 + q * 4 + v) * 3 + j) * D + ib * 16 + m] = accg[i][f][j][v];
 #pragma unroll
       for (int a = 0; a < AB; ++a)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) udst[static_cast<int64_t>(ib * 16 + q * 4 + v) * A + a * 16 + m] = accu[a][v];
+        for (int v = 0; v < 4; ++v) udst[static_cast<int64_t>(ib * 16 + q * 4 + v) * A + a * 16 + m] = accu[i][a][v];
     }
     return;
   }
