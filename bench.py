@@ -276,7 +276,7 @@ def main():
     extra = {"graph_build_s": round(t_build, 2), "epoch_sampling_s": round(t_sample, 3),
              "epoch_triplets": int(epoch.shape[0]), "last_loss": loss_val,
              "edge_layers_per_s": nnz * L * 2 * K / dt}
-    if args.big_batch and epoch.shape[0] >= args.big_batch * 3:
+    if args.big_batch and epoch.shape[0] >= args.big_batch * 3 and not sharded:
         BB = args.big_batch
         bb = [epoch[k * BB:(k + 1) * BB] for k in range(3)]
         run_steps(bb[:1])
@@ -313,7 +313,8 @@ def main():
 
     if rank == 0:
         mname = "LightGCN" if args.model == "lightgcn" else "NGCF"
-        out = {"metric": f"BPR triplets/sec, {mname} {L}-layer dim{D}, 1M users x 1M items x 50M edges",
+        size = "1M users x 1M items x 50M edges" if args.scale == 1.0 else f"{nu} users x {ni} items x {ne} edges"
+        out = {"metric": f"BPR triplets/sec, {mname} {L}-layer dim{D}, {size}",
                "value": K * B / dt, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": dt / K * 1e3, "higher_is_better": True,
                "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
