@@ -1,0 +1,127 @@
+"""GPU: the training-driver surface end to end -- Basic_train / Early_stop / Basic_test wiring, the
+two-phase TGCN schedule with one shared Adam (com.py:65-74), node / message dropout paths, the TransTag producer."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tagrec_amd as T
+from tagrec_amd import help as H
+
+DEV = torch.device("cuda:0")
+
+
+def test_basic_train_run_lightgcn(tmp_path):
+    """lightgcn_comp (com.py:21-29) re-created with tagrec_amd: loss decreases, eval runs every
+    test_interval epochs, the best state_dict is saved with the reference's key names."""
+    ds = T.synth.make_cf_dataset(120, 90, 2500, seed=8)
+    cfg = T.get_config("lightgcn", use_tag=False, dim_layer_list=[32, 32], dim_latent=32, device=DEV, epochs=4,
+                       test_interval=2, train_batch=256, test_batch=50)
+    torch.manual_seed(1)
+    model = T.LightGCN(ds, config=cfg)
+    train = T.Basic_train([T.BPR_training_data(ds, config=cfg, seed=3)], [model.loss],
+                          [T.Adam(model.parameters(), lr=0.01)], T.Basic_test(ds, config=cfg),
+                          types.SimpleNamespace(out_dir=str(tmp_path)), config=cfg)
+    hist = train.run(model, verbose=False)
+    assert len(hist) == 4
+    first, last = np.mean(hist[0][2]), np.mean(hist[-1][2])
+    assert last < first
+    assert train.early_stop.best_result is not None and 0 <= train.early_stop.best_result["recall"][1] <= 1
+    sd = torch.load(tmp_path / "model.pth.tar", weights_only=True)
+    assert list(sd.keys()) == ["embed.0", "embed.1"] and sd["embed.0"].shape == (120, 32)
+    # the saved state loads back into a fresh model and reproduces its predictions
+    m2 = T.LightGCN(ds, config=cfg)
+    m2.load_state_dict(sd)
+    m2.eval()
+    assert m2.predict_rating(torch.arange(5, device=DEV)).shape == (5, 90)
+
+
+def test_tgcn_two_phase_epoch_shared_adam():
+    """tgcn_comp: phase 0 = BPR through the propagation, phase 1 = TransTag on the ego tables, ONE Adam
+    instance for both (its step counter advances in both phases)."""
+    ds = T.synth.make_cf_dataset(60, 50, 700, seed=9, n_tag=20, n_assign=500)
+    cfg = T.get_config("tgcn", dim_layer_list=[16], dim_latent=16, device=DEV, neighbor_k=5, train_batch=128,
+                       transtag_batch=128, epochs=2, test_interval=10)
+    torch.manual_seed(2)
+    model = T.TGCN(ds, config=cfg)
+    opt = T.Adam(model.parameters(), lr=0.01)
+    bpr, tt = T.BPR_training_data(ds, config=cfg, seed=1), T.TransTag_training_data(ds, config=cfg, seed=1)
+    # producer properties (transe_training_data.py:42-70): rows (u, t, i+, i-), i- never a tagged item of (u, t)
+    a = tt.all_train_data.cpu().numpy()
+    uit = np.asarray(ds.uit_data)
+    assert a.shape == (len(uit), 4)
+    have = set(map(tuple, uit[:, [0, 2, 1]].tolist()))
+    assert all((int(u), int(t), int(n)) not in have for u, t, _, n in a)
+    assert np.array_equal(a[:, :3], uit[:, [0, 2, 1]])                      # not shuffled
+    train = T.Basic_train([bpr, tt], [model.loss, model.transtag_loss], [opt, opt], None, None, config=cfg)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    hist = train.run(model, verbose=False)
+    assert [h[1] for h in hist] == [0, 1, 0, 1]
+    n_steps = sum(len(h[2]) for h in hist)
+    assert opt.step_count == n_steps and all(np.isfinite(h[2]).all() for h in hist)
+    moved = [k for k, v in model.named_parameters() if not torch.equal(v, before[k])]
+    assert "embed.tag" in moved and "layer.0.Wf" in moved
+
+
+def test_node_drop_semantics():
+    """`node_drop` (adj.py:170-191): identity at rate 0 or in eval; otherwise kept edges are divided by the keep
+    rate and about that fraction survives."""
+    ds = T.synth.make_cf_dataset(200, 150, 6000, seed=3)
+    g = T.creat_adj(ds, False, "bi_norm", 1, DEV)
+    assert H.node_drop(g, 0.0, True) is g and H.node_drop(g, 0.3, False) is g
+    torch.manual_seed(0)
+    d = H.node_drop(g, 0.25, True)
+    frac = d.nnz / g.nnz
+    assert 0.70 < frac < 0.80
+    # surviving values = original / 0.75
+    dense_g = torch.zeros(g.shape, device=DEV)
+    rows = torch.repeat_interleave(torch.arange(g.shape[0], device=DEV), g.rowptr[1:] - g.rowptr[:-1])
+    dense_g[rows, g.col.long()] = g.val
+    rows_d = torch.repeat_interleave(torch.arange(d.shape[0], device=DEV), d.rowptr[1:] - d.rowptr[:-1])
+    np.testing.assert_allclose(d.val.cpu().numpy(), (dense_g[rows_d, d.col.long()] / 0.75).cpu().numpy(), rtol=1e-6)
+    with pytest.raises(AssertionError):
+        H.node_drop(g, 1.0, True)
+
+
+def test_dropout_paths_run_and_eval_is_deterministic():
+    """message / node dropout take the operator-by-operator path in training; eval ignores them."""
+    ds = T.synth.make_cf_dataset(80, 60, 1200, seed=4)
+    cfg = T.get_config("lightgcn", use_tag=False, dim_layer_list=[32, 32], dim_latent=32, device=DEV,
+                       message_drop_list=[0.2, 0.2], node_drop=0.1)
+    torch.manual_seed(0)
+    m = T.LightGCN(ds, config=cfg)
+    b = torch.from_numpy(T.synth.sample_bpr_epoch(ds, 0)[:64]).to(DEV)
+    m.train()
+    l1 = m.loss(b)
+    sum(l1).backward()
+    assert torch.isfinite(m.table.grad).all() and float(m.table.grad.abs().sum()) > 0
+    m.eval()
+    u1, i1 = m.forward()
+    u2, i2 = m.forward()
+    assert torch.equal(u1, u2) and torch.equal(i1, i2)
+    ref = T.LightGCN(ds, config=T.get_config("lightgcn", use_tag=False, dim_layer_list=[32, 32], dim_latent=32, device=DEV))
+    ref.load_state_dict(m.state_dict())
+    ref.eval()
+    np.testing.assert_allclose(ref.forward()[0].detach().cpu().numpy(), u1.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_predict_rating_cache_is_dropped_on_train():
+    ds = T.synth.make_cf_dataset(50, 40, 500, seed=6)
+    cfg = T.get_config("lightgcn", use_tag=False, dim_layer_list=[16], dim_latent=16, device=DEV)
+    m = T.LightGCN(ds, config=cfg)
+    users = torch.arange(10, device=DEV)
+    m.eval()
+    r1 = m.predict_rating(users)
+    assert m._eval_cache is not None
+    m.train()
+    assert m._eval_cache is None
+    opt = T.Adam(m.parameters(), lr=0.1)
+    lossx = m.loss(torch.from_numpy(T.synth.sample_bpr_epoch(ds, 0)[:64]).to(DEV))
+    sum(lossx).backward()
+    opt.step()
+    m.eval()
+    r2 = m.predict_rating(users)
+    assert not torch.equal(r1, r2)
