@@ -198,3 +198,51 @@ def test_tgcn_fused_equals_operator_path(golden):
     scale = max(float(np.abs(v).max()) for v in res[1][1].values())
     for k in res[1][1]:
         _close(res[0][1][k], res[1][1][k], k, rtol=2e-3, scale=scale)
+
+
+def test_c4_size_kernels_on_sampled_nodes():
+    """At the C4 row count (1M nodes of one type, D=128, k=25) the oracle is too slow and the reference cannot
+    materialise the block at all; check the kernels on sampled nodes against the operator form evaluated on
+    just those nodes, plus run-to-run determinism of forward and of the pull-form backward."""
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    n, m, D, A, k, nw, C, V = 1_000_000, 1_000_000, 128, 32, 25, 16, 32, 8
+    r = lambda *s, sc=1.0: torch.randn(*s, device=DEV, generator=gen) * sc
+    # --- neighbour attention
+    P, Q, WT, v, Ej = r(n, A, sc=0.3), r(m, A, sc=0.3), r(nw + 1, A, sc=0.3), r(A), r(m, D, sc=0.5)
+    WT[0] = 0
+    idx = torch.randint(0, m + 1, (n, k), device=DEV, generator=gen, dtype=torch.int32)
+    widx = torch.where(idx > 0, torch.randint(1, nw + 1, (n, k), device=DEV, generator=gen, dtype=torch.int32),
+                       torch.zeros_like(idx))
+    out = TG.neighbour_attention(P, Q, WT, v, Ej, idx, widx)
+    pick = torch.randint(0, n, (500,), device=DEV, generator=gen)
+    ji = idx[pick].long()
+    Qp = torch.cat([Q.new_zeros(1, A), Q])[ji]                       # pad row 0 = zeros
+    Ep = torch.cat([Ej.new_zeros(1, D), Ej])[ji]
+    s = (torch.relu(P[pick, None, :] + WT[widx[pick].long()] + Qp) * v).sum(-1)
+    want = (torch.softmax(s, dim=1)[..., None] * Ep).sum(1)
+    np.testing.assert_allclose(out[pick].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert torch.equal(out, TG.neighbour_attention(P, Q, WT, v, Ej, idx, widx))
+    # pull-form backward: deterministic, and dEj equals the scatter form up to atomic ordering
+    inv = TG.InverseTable(idx, m)
+    up = r(n, D)
+    grads = []
+    for tab in (inv, inv, None):
+        leaves = [t.clone().requires_grad_() for t in (P, Q, Ej)]
+        o = TG.neighbour_attention(leaves[0], leaves[1], WT, v, leaves[2], idx, widx, tab)
+        (o * up).sum().backward()
+        grads.append([t.grad for t in leaves])
+    assert all(torch.equal(a, b) for a, b in zip(grads[0], grads[1]))
+    for a, b in zip(grads[0], grads[2]):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    del grads, inv, out, Qp, Ep
+    # --- fused dense block, forward, on sampled nodes
+    ts = [r(n, D, sc=0.5) for _ in range(3)]
+    prm = [r(D, A, sc=0.2), r(1, A, sc=0.1), r(1, A), r(C, 1, 3, 1, sc=0.5), r(V, 1, 1, D, sc=0.2), r(V, 1, 2, D, sc=0.2),
+           r(V, 1, 3, D, sc=0.2), r(C * D + 6 * V, D, sc=0.05), r(1, D, sc=0.1)]
+    U, q, p, wb, w1, w2, w3, Wf, bf = prm
+    with torch.no_grad():
+        got = TG._FusedDense.apply(ts[0], ts[1], ts[2], U, q.reshape(-1), p.reshape(-1), wb.reshape(C, 3), w1.reshape(V, -1),
+                                   w2.reshape(V, -1), w3.reshape(V, -1), Wf, bf.reshape(-1), 65536)
+        pick = torch.randint(0, n, (2000,), device=DEV, generator=gen)
+        want = TG._dense_block(torch.stack([t[pick].double() for t in ts], 1), *[x.double() for x in prm])
+    np.testing.assert_allclose(got[pick].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=3e-5)
