@@ -108,6 +108,18 @@ int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, int D,
                        const int64_t* trip, int64_t B, const float* coef, const float* g, float reg,
                        float* dU, float* dI, float* dUreg, float* dIreg, void* stream);
 
+/* ---- TransTag phase of TGCN (tgcn.py:251-261, loss.py:35-41, 27-32) on the EGO tables -------------------------
+ * quad: int64 [B,4] = (user, tag, pos_item, neg_item).  fwd: loss_out[0] = mean relu(margin + ||u+t-p|| - ||u+t-n||),
+ * loss_out[1] = l2reg_loss(u, t, p, n) (unweighted); dist [B,2] keeps the two distances; partials: 2*ceil(B/4) floats.
+ * bwd: float-atomic scatter-add of g[0]*d loss + g[1]*d reg into caller-zeroed dEu / dEi / dEt (g = two upstream
+ * gradients on the device, NULL = (1,1)). */
+int tagrec_transtag_fwd_f32(const float* Eu, const float* Ei, const float* Et, int64_t ld, int D,
+                            const int64_t* quad, int64_t B, float margin, float* dist, float* partials,
+                            float* loss_out, void* stream);
+int tagrec_transtag_bwd_f32(const float* Eu, const float* Ei, const float* Et, int64_t ld, int D,
+                            const int64_t* quad, int64_t B, float margin, const float* dist, const float* g,
+                            float* dEu, float* dEi, float* dEt, void* stream);
+
 /* ---- Adam (torch.optim.Adam defaults as used at com.py:14,25,69), one fused pass -----------------
  *   m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
 int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,

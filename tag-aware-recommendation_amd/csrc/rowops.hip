@@ -172,6 +172,74 @@ __global__ __launch_bounds__(kThreads) void bpr_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// TransTag phase (tgcn.py:251-261, loss.py:35-41): rows (user, tag, pos_item, neg_item) of the EGO tables,
+//   loss = mean relu(margin + ||u + t - p||_2 - ||u + t - n||_2),  reg = 0.5 (|u|^2 + |t|^2 + |p|^2 + |n|^2) / B.
+// One wave per row; forward keeps the two distances for the backward scatter.
+__global__ __launch_bounds__(kThreads) void transtag_fwd_kernel(const float* __restrict__ Eu, const float* __restrict__ Ei,
+                                                                const float* __restrict__ Et, int64_t ld, int D,
+                                                                const int64_t* __restrict__ quad, int64_t B, float margin,
+                                                                float* __restrict__ dist, float* __restrict__ partials) {
+  __shared__ float sh[2][kThreads / kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = threadIdx.x >> 6;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + w;
+  float loss = 0.f, reg = 0.f;
+  if (b < B) {
+    const float* u = Eu + quad[4 * b] * ld;
+    const float* t = Et + quad[4 * b + 1] * ld;
+    const float* p = Ei + quad[4 * b + 2] * ld;
+    const float* n = Ei + quad[4 * b + 3] * ld;
+    float sp = 0.f, sn = 0.f, ss = 0.f;
+    for (int k = lane; k < D; k += kWave) {
+      const float uv = u[k], tv = t[k], pv = p[k], nv = n[k];
+      const float h = uv + tv;
+      sp = fmaf(h - pv, h - pv, sp);
+      sn = fmaf(h - nv, h - nv, sn);
+      ss = fmaf(uv, uv, fmaf(tv, tv, fmaf(pv, pv, fmaf(nv, nv, ss))));
+    }
+    const float ps = sqrtf(wave_sum(sp)), ns = sqrtf(wave_sum(sn));
+    loss = fmaxf(margin + ps - ns, 0.f);
+    reg = 0.5f * wave_sum(ss);
+    if (lane == 0) { dist[2 * b] = ps; dist[2 * b + 1] = ns; }
+  }
+  if (lane == 0) { sh[0][w] = loss; sh[1][w] = reg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f, g = 0.f;
+    for (int i = 0; i < kThreads / kWave; ++i) { l += sh[0][i]; g += sh[1][i]; }
+    partials[2 * blockIdx.x] = l;
+    partials[2 * blockIdx.x + 1] = g;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void transtag_bwd_kernel(const float* __restrict__ Eu, const float* __restrict__ Ei,
+                                                                const float* __restrict__ Et, int64_t ld, int D,
+                                                                const int64_t* __restrict__ quad, int64_t B, float margin,
+                                                                const float* __restrict__ dist, const float* __restrict__ g,
+                                                                float inv_b, float* __restrict__ dEu, float* __restrict__ dEi,
+                                                                float* __restrict__ dEt) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float g0 = (g ? g[0] : 1.f) * inv_b, g1 = (g ? g[1] : 1.f) * inv_b;
+  const int64_t iu = quad[4 * b] * ld, it = quad[4 * b + 1] * ld, ip = quad[4 * b + 2] * ld, in_ = quad[4 * b + 3] * ld;
+  const float ps = dist[2 * b], ns = dist[2 * b + 1];
+  const bool live = margin + ps - ns > 0.f;
+  // d||x||/dx = x / ||x||, taken as 0 at x = 0 (what torch's norm backward does)
+  const float cp = (live && ps > 0.f) ? g0 / ps : 0.f;
+  const float cn = (live && ns > 0.f) ? g0 / ns : 0.f;
+  for (int k = lane; k < D; k += kWave) {
+    const float uv = Eu[iu + k], tv = Et[it + k], pv = Ei[ip + k], nv = Ei[in_ + k];
+    const float h = uv + tv;
+    const float dh = cp * (h - pv) - cn * (h - nv);
+    atomicAdd(&dEu[iu + k], dh + g1 * uv);
+    atomicAdd(&dEt[it + k], dh + g1 * tv);
+    atomicAdd(&dEi[ip + k], -cp * (h - pv) + g1 * pv);
+    atomicAdd(&dEi[in_ + k], cn * (h - nv) + g1 * nv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adam, 16 B per lane, grid-stride.  28 B of traffic per element.
 __global__ __launch_bounds__(kThreads) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
                                                         float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
@@ -261,6 +329,32 @@ extern "C" int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, in
   const int64_t blocks = (B + 3) / 4;
   bpr_bwd_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
       U, I, ld, D, Ureg, Ireg, ldreg, Dreg, trip, B, coef, g, reg, 1.0f / static_cast<float>(B), dU, dI, dUreg, dIreg);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_transtag_fwd_f32(const float* Eu, const float* Ei, const float* Et, int64_t ld, int D,
+                                       const int64_t* quad, int64_t B, float margin, float* dist, float* partials,
+                                       float* loss_out, void* stream) {
+  TAGREC_REQUIRE(Eu && Ei && Et && quad && dist && partials && loss_out, "transtag_fwd: null pointer");
+  TAGREC_REQUIRE(B >= 1 && D >= 1 && ld >= D, "transtag_fwd: bad shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t blocks = (B + 3) / 4;
+  transtag_fwd_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, s>>>(Eu, Ei, Et, ld, D, quad, B, margin, dist, partials);
+  TAGREC_LAUNCH_CHECK();
+  bpr_reduce_kernel<<<1, kThreads, 0, s>>>(partials, blocks, 1.0f / static_cast<float>(B), loss_out);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_transtag_bwd_f32(const float* Eu, const float* Ei, const float* Et, int64_t ld, int D,
+                                       const int64_t* quad, int64_t B, float margin, const float* dist, const float* g,
+                                       float* dEu, float* dEi, float* dEt, void* stream) {
+  TAGREC_REQUIRE(Eu && Ei && Et && quad && dist && dEu && dEi && dEt, "transtag_bwd: null pointer");
+  TAGREC_REQUIRE(B >= 1 && D >= 1 && ld >= D, "transtag_bwd: bad shape");
+  const int64_t blocks = (B + 3) / 4;
+  transtag_bwd_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+      Eu, Ei, Et, ld, D, quad, B, margin, dist, g, 1.0f / static_cast<float>(B), dEu, dEi, dEt);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

@@ -150,6 +150,45 @@ def l2reg_loss(*embs):
     return 0.5 * tot / float(embs[0].shape[0])
 
 
+class _TransTagLoss(torch.autograd.Function):
+    """TransTag margin loss + L2 on table rows selected by a [B,4] (user, tag, pos_item, neg_item) batch;
+    the gathers are part of the kernel.  Returns [loss, l2reg_loss (unweighted)]."""
+
+    @staticmethod
+    def forward(ctx, Eu, Ei, Et, quad, margin):
+        for t, nm in ((Eu, "Eu"), (Ei, "Ei"), (Et, "Et")):
+            _lib.require_gpu_tensor(t, torch.float32, "transtag " + nm)
+        quad = _lib.require_gpu_tensor(quad.contiguous(), torch.int64, "transtag batch")
+        B, D = quad.shape[0], Eu.shape[1]
+        dist = torch.empty(B, 2, dtype=torch.float32, device=Eu.device)
+        partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=Eu.device)
+        out = torch.empty(2, dtype=torch.float32, device=Eu.device)
+        _lib.check(_lib.load().tagrec_transtag_fwd_f32(_lib.ptr(Eu), _lib.ptr(Ei), _lib.ptr(Et), Eu.stride(0), D,
+                                                       _lib.ptr(quad), B, float(margin), _lib.ptr(dist), _lib.ptr(partials),
+                                                       _lib.ptr(out), _lib.stream_ptr()), "transtag_fwd")
+        ctx.save_for_backward(Eu, Ei, Et, quad, dist)
+        ctx.margin = float(margin)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Eu, Ei, Et, quad, dist = ctx.saved_tensors
+        dEu, dEi, dEt = torch.zeros_like(Eu), torch.zeros_like(Ei), torch.zeros_like(Et)
+        _lib.check(_lib.load().tagrec_transtag_bwd_f32(_lib.ptr(Eu), _lib.ptr(Ei), _lib.ptr(Et), Eu.stride(0), Eu.shape[1],
+                                                       _lib.ptr(quad), quad.shape[0], ctx.margin, _lib.ptr(dist),
+                                                       _lib.ptr(g.contiguous()), _lib.ptr(dEu), _lib.ptr(dEi), _lib.ptr(dEt),
+                                                       _lib.stream_ptr()), "transtag_bwd")
+        return dEu, dEi, dEt, None, None
+
+
+def transtag_batch_loss(Eu, Ei, Et, quad, margin):
+    """(transtag_loss, l2reg_loss) of a [B,4] batch against the user / item / tag tables (tgcn.py:251-261)."""
+    if not (Eu.stride(0) == Ei.stride(0) == Et.stride(0) and Eu.shape[1] == Ei.shape[1] == Et.shape[1]):
+        raise _lib.TagrecError("transtag_batch_loss: tables must share width and row stride")
+    out = _TransTagLoss.apply(Eu, Ei, Et, quad, margin)
+    return out[0], out[1]
+
+
 def transtag_loss(head_e, rela_e, pos_tail_e, neg_tail_e, margin=0):
     """mean relu(margin + ||h+r-t+|| - ||h+r-t-||)  (loss.py:35-41)."""
     if not head_e.is_cuda:

@@ -450,12 +450,10 @@ class TGCN(nn.Module):
         return loss, self.reg * reg_loss
 
     def transtag_loss(self, batch_data):
-        batch_data = batch_data.to(self.device, torch.int64)
-        user, tag, pos_item, neg_item = batch_data.T
+        batch_data = batch_data.to(self.device, torch.int64).contiguous()
         eu, ei, et = self.get_ego_embed()
-        ue, te, pe, ne = eu[user], et[tag], ei[pos_item], ei[neg_item]
-        loss = H.transtag_loss(ue, te, pe, ne, self.margin)
-        return loss, self.transtag_reg * H.l2reg_loss(ue, te, pe, ne)
+        loss, reg_loss = H.transtag_batch_loss(eu, ei, et, batch_data, self.margin)
+        return loss, self.transtag_reg * reg_loss
 
     def predict_rating(self, users):
         if self.training or self._eval_cache is None:
