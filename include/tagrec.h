@@ -108,6 +108,13 @@ int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, int D,
                        const int64_t* trip, int64_t B, const float* coef, const float* g, float reg,
                        float* dU, float* dI, float* dUreg, float* dIreg, void* stream);
 
+/* ---- negative sampler (train_data/utils.py:19-28, 31-40) -------------------------------------------------------
+ * For each of n_rows positive rows with left id left[e] (a user, or a (user, tag) pair id): one uniform draw in
+ * [0, n_right), re-drawn while it is in the left id's sorted positive list cols[rowptr[l] .. rowptr[l+1]).
+ * Draw t of row e is a pure function of (seed, e, t): reproducible whatever the launch geometry. */
+int tagrec_sample_negative_i64(const int64_t* left, int64_t n_rows, const int64_t* rowptr, const int32_t* cols,
+                               int64_t n_left, int64_t n_right, uint64_t seed, int64_t* neg, void* stream);
+
 /* ---- TransTag phase of TGCN (tgcn.py:251-261, loss.py:35-41, 27-32) on the EGO tables -------------------------
  * quad: int64 [B,4] = (user, tag, pos_item, neg_item).  fwd: loss_out[0] = mean relu(margin + ||u+t-p|| - ||u+t-n||),
  * loss_out[1] = l2reg_loss(u, t, p, n) (unweighted); dist [B,2] keeps the two distances; partials: 2*ceil(B/4) floats.

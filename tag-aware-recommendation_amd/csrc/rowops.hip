@@ -172,6 +172,42 @@ __global__ __launch_bounds__(kThreads) void bpr_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Negative sampler (train_data/utils.py:19-28 `sample_neg_item`, :31-40 `sample_neg_tail`): one uniform draw in
+// [0, n_right) per positive row, re-drawn while (left id, draw) is a positive pair.  The positives of a left id are
+// the sorted row `cols[rowptr[l] .. rowptr[l+1])`, so membership is a binary search in that row.  Counter-based
+// generator: draw t of row e under `seed` is a pure function of (seed, e, t) -- reproducible, order-free.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {          // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kThreads) void sample_negative_kernel(const int64_t* __restrict__ left, int64_t n_rows,
+                                                                   const int64_t* __restrict__ rowptr,
+                                                                   const int32_t* __restrict__ cols, int64_t n_right,
+                                                                   uint64_t seed, int64_t* __restrict__ neg) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= n_rows) return;
+  const int64_t l = left[e];
+  const int64_t lo0 = rowptr[l], hi0 = rowptr[l + 1];
+  const uint64_t base = mix64(seed ^ mix64(static_cast<uint64_t>(e)));
+  int64_t draw = 0;
+  for (uint32_t t = 0; t < 4096u; ++t) {       // the row cannot cover all of [0, n_right): terminates; bound anyway
+    // 64-bit multiply-shift maps a uniform 64-bit word onto [0, n_right) without modulo bias worth measuring
+    const uint64_t r = mix64(base + t);
+    draw = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(n_right)));
+    int64_t lo = lo0, hi = hi0;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (cols[mid] < draw) lo = mid + 1; else hi = mid;
+    }
+    if (lo == hi0 || cols[lo] != draw) break;
+  }
+  neg[e] = draw;
+}
+
+// ------------------------------------------------------------------------------------------------
 // TransTag phase (tgcn.py:251-261, loss.py:35-41): rows (user, tag, pos_item, neg_item) of the EGO tables,
 //   loss = mean relu(margin + ||u + t - p||_2 - ||u + t - n||_2),  reg = 0.5 (|u|^2 + |t|^2 + |p|^2 + |n|^2) / B.
 // One wave per row; forward keeps the two distances for the backward scatter.
@@ -329,6 +365,18 @@ extern "C" int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, in
   const int64_t blocks = (B + 3) / 4;
   bpr_bwd_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
       U, I, ld, D, Ureg, Ireg, ldreg, Dreg, trip, B, coef, g, reg, 1.0f / static_cast<float>(B), dU, dI, dUreg, dIreg);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_sample_negative_i64(const int64_t* left, int64_t n_rows, const int64_t* rowptr, const int32_t* cols,
+                                          int64_t n_left, int64_t n_right, uint64_t seed, int64_t* neg, void* stream) {
+  TAGREC_REQUIRE(left && rowptr && neg && (cols || n_rows == 0), "sample_negative: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && n_left >= 1 && n_right >= 1, "sample_negative: bad shape");
+  if (n_rows == 0) return TAGREC_OK;
+  const int64_t blocks = (n_rows + kThreads - 1) / kThreads;
+  sample_negative_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+      left, n_rows, rowptr, cols, n_right, seed, neg);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

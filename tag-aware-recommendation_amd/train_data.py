@@ -6,9 +6,10 @@
 
 The reference samples negatives in a forked `multiprocessing.Pool` with a Python
 rejection loop per edge (train_data/utils.py:19-28) and copies the epoch's
-[E,3] array to the device.  Here the epoch is sampled ON the device: uniform
-draws, membership test by binary search in the sorted (user, item) keys,
-re-draw of the collisions until none is left, then a device-side shuffle.
+[E,3] array to the device.  Here the epoch is sampled ON the device by a HIP
+kernel (csrc/rowops.hip `sample_negative_kernel`): per edge, counter-based
+uniform draws, membership test by binary search in the user's sorted positive
+list, re-draw until a non-positive comes up; then a device-side shuffle.
 Same distribution (one uniform non-train item per train edge); the reference's
 own stream is not reproducible from its seed, so parity runs use
 `Fixed_training_data` with arrays shared by both sides.
@@ -16,6 +17,7 @@ own stream is not reproducible from its seed, so parity runs use
 import numpy as np
 import torch
 
+from . import _lib
 from .config import CFG as _GLOBAL_CFG
 
 
@@ -44,19 +46,25 @@ class Abstract_training_data:
                 yield self.all_train_data[i:i + self.batch_size]
 
 
-def _reject_resample(keys_sorted, left, n_right, gen):
-    """One uniform draw in [0, n_right) per row of `left`, re-drawn while left*n_right+draw is in keys_sorted."""
-    dev = left.device
-    neg = torch.randint(0, n_right, left.shape, device=dev, generator=gen)
-    todo = torch.arange(left.numel(), device=dev)
-    while todo.numel():
-        k = left[todo] * n_right + neg[todo]
-        pos = torch.searchsorted(keys_sorted, k).clamp_(max=keys_sorted.numel() - 1)
-        bad = keys_sorted[pos] == k
-        todo = todo[bad]
-        if todo.numel():
-            neg[todo] = torch.randint(0, n_right, todo.shape, device=dev, generator=gen)
-    return neg
+class _Positives:
+    """Sorted positive lists per left id as a device CSR (rowptr int64, cols int32), built once."""
+
+    def __init__(self, left, right, n_left, n_right):
+        key = torch.unique(left * n_right + right)
+        l = torch.div(key, n_right, rounding_mode="floor")
+        self.rowptr = torch.zeros(n_left + 1, dtype=torch.int64, device=left.device)
+        torch.cumsum(torch.bincount(l, minlength=n_left), 0, out=self.rowptr[1:])
+        self.cols = (key - l * n_right).to(torch.int32).contiguous()
+        self.n_left, self.n_right = int(n_left), int(n_right)
+
+    def sample(self, left, seed):
+        """One uniform non-positive draw per entry of `left` (HIP kernel, counter-based generator)."""
+        left = left.contiguous()
+        neg = torch.empty_like(left)
+        _lib.check(_lib.load().tagrec_sample_negative_i64(_lib.ptr(left), left.numel(), _lib.ptr(self.rowptr),
+                                                          _lib.ptr(self.cols), self.n_left, self.n_right, int(seed),
+                                                          _lib.ptr(neg), _lib.stream_ptr()), "sample_negative")
+        return neg
 
 
 class BPR_training_data(Abstract_training_data):
@@ -68,15 +76,18 @@ class BPR_training_data(Abstract_training_data):
         pos = data.edge_index["train"]
         self.pos_inter = (pos if isinstance(pos, torch.Tensor) else torch.from_numpy(np.asarray(pos))).to(
             self.device, torch.int64)
-        self._keys = torch.sort(self.pos_inter[:, 0] * self.num + self.pos_inter[:, 1]).values
+        self._pos = _Positives(self.pos_inter[:, 0], self.pos_inter[:, 1], self.num_user, self.num)
+        self._seed = int(cfg["seed"] if seed is None else seed)
+        self._epoch = 0
         self._gen = torch.Generator(device=self.device)
-        self._gen.manual_seed(cfg["seed"] if seed is None else seed)
+        self._gen.manual_seed(self._seed)
         self.all_train_data = self.get_all_training_data()
         self.tot_inter = self.all_train_data.shape[0] // self.batch_size
 
     def get_all_training_data(self):
-        u, i = self.pos_inter[:, 0], self.pos_inter[:, 1]
-        neg = _reject_resample(self._keys, u, self.num, self._gen)
+        u, i = self.pos_inter[:, 0].contiguous(), self.pos_inter[:, 1]
+        neg = self._pos.sample(u, (self._seed << 20) + self._epoch)      # a fresh stream every epoch
+        self._epoch += 1
         data = torch.stack([u, i, neg], dim=1)
         perm = torch.randperm(data.shape[0], device=self.device, generator=self._gen)
         return data[perm].contiguous()
@@ -112,13 +123,16 @@ class TransTag_training_data(Abstract_training_data):
         uit = data.uit_data if isinstance(data.uit_data, torch.Tensor) else torch.from_numpy(np.asarray(data.uit_data))
         uit = uit.to(self.device, torch.int64)
         self.uti = uit[:, [0, 2, 1]].contiguous()
-        self._left = self.uti[:, 0] * n_tag + self.uti[:, 1]            # (u, t) pair id
-        self._keys = torch.sort(self._left * self.num + self.uti[:, 2]).values
-        self._gen = torch.Generator(device=self.device)
-        self._gen.manual_seed((cfg["seed"] if seed is None else seed) + 1)
+        # positives of a (user, tag) pair = the items it was assigned to; pair ids are compacted so the CSR stays small
+        pair = self.uti[:, 0] * n_tag + self.uti[:, 1]
+        upair, self._left = torch.unique(pair, return_inverse=True)
+        self._pos = _Positives(self._left, self.uti[:, 2], upair.numel(), self.num)
+        self._seed = int(cfg["seed"] if seed is None else seed) + 1
+        self._epoch = 0
         self.all_train_data = self.get_all_training_data()
         self.tot_inter = self.all_train_data.shape[0] // self.batch_size
 
     def get_all_training_data(self):
-        neg = _reject_resample(self._keys, self._left, self.num, self._gen)
+        neg = self._pos.sample(self._left, (self._seed << 20) + self._epoch)
+        self._epoch += 1
         return torch.cat([self.uti, neg[:, None]], dim=1).contiguous()
