@@ -260,7 +260,7 @@ template <int D, int DOUT>
 int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n, const float* U, const float* qv,
                     const float* pv, const float* wb, const float* w1, const float* w2, const float* w3, const float* Wf,
                     const float* bf, float* bw_out, float* out, hipStream_t s) {
-  constexpr int NS = (D >= 128) ? 1 : 2;
+  constexpr int NS = (D >= 64) ? 1 : 2;   // measured at D = 128: two waves per SIMD with one subtile beat one wave with two
   const int64_t tiles = (n + 16 * NS - 1) / (16 * NS);
   int64_t blocks = (tiles + 3) / 4;
   if (blocks > 256 * 2) blocks = 256 * 2;
