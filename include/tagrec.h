@@ -108,6 +108,16 @@ int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, int D,
                        const int64_t* trip, int64_t B, const float* coef, const float* g, float reg,
                        float* dU, float* dI, float* dUreg, float* dIreg, void* stream);
 
+/* ---- evaluation: sigmoid(U_b I^T) -> mask train positives -> top-K, fused (lightgcn.py:84-89, basic_test.py:36-50) --
+ * U / I: propagated user / item tables, row-major [*, D].  users: int64 [n_users] ids to score.  train_ptr int64
+ * [n_user_total + 1] / train_items int32: each user's train items, sorted (the rows basic_test.py:47 overwrites with
+ * -1024; here they are simply never admitted).  top_idx int64 [n_users, K]: item ids by descending sigmoid score,
+ * ties to the lower id, -1 if fewer than K items remain; top_val [n_users, K] (may be NULL): the scores.
+ * D in {16,32,64,128,192,256,384,512}, K <= 64. */
+int tagrec_eval_topk_f32(const float* U, const float* I, int64_t n_item, int D, const int64_t* users,
+                         int64_t n_users, const int64_t* train_ptr, const int32_t* train_items, int K,
+                         int64_t* top_idx, float* top_val, void* stream);
+
 /* ---- negative sampler (train_data/utils.py:19-28, 31-40) -------------------------------------------------------
  * For each of n_rows positive rows with left id left[e] (a user, or a (user, tag) pair id): one uniform draw in
  * [0, n_right), re-drawn while it is in the left id's sorted positive list cols[rowptr[l] .. rowptr[l+1]).

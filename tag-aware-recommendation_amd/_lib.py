@@ -56,6 +56,8 @@ _SIGNATURES = {
     "tagrec_tgcn_fuse_wf_workspace": [c_int, c_int],
     "tagrec_tgcn_fuse_wf_result": [c_int, c_int],
     "tagrec_tgcn_fuse_wf_f32": [c_void_p] * 10 + [c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p],
+    "tagrec_eval_topk_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
+                             c_void_p, c_void_p],
     "tagrec_sample_negative_i64": [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, ctypes.c_uint64, c_void_p, c_void_p],
     "tagrec_transtag_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_float, c_void_p, c_void_p,
                                 c_void_p, c_void_p],

@@ -13,7 +13,24 @@ device from sorted (user, item) keys, one host read at the end.
 import numpy as np
 import torch
 
+from . import _lib
 from .config import CFG as _GLOBAL_CFG
+
+FUSED_WIDTHS = (16, 32, 64, 128, 192, 256, 384, 512)
+
+
+def fused_topk(user_table, item_table, users, train_ptr, train_items, k):
+    """Top-k item ids per user by sigmoid(u . i), train positives excluded -- one fused HIP pass over the item
+    table (csrc/eval.hip) instead of a [users, n_item] rating matrix + mask + torch.topk."""
+    U = _lib.require_gpu_tensor(user_table.contiguous(), torch.float32, "eval user table")
+    I = _lib.require_gpu_tensor(item_table.contiguous(), torch.float32, "eval item table")
+    users = users.to(U.device, torch.int64).contiguous()
+    top = torch.empty(users.numel(), k, dtype=torch.int64, device=U.device)
+    val = torch.empty(users.numel(), k, dtype=torch.float32, device=U.device)
+    _lib.check(_lib.load().tagrec_eval_topk_f32(_lib.ptr(U), _lib.ptr(I), I.shape[0], U.shape[1], _lib.ptr(users),
+                                                users.numel(), _lib.ptr(train_ptr), _lib.ptr(train_items), k,
+                                                _lib.ptr(top), _lib.ptr(val), _lib.stream_ptr()), "eval_topk")
+    return top, val
 
 
 def _edge_keys(user_items, n_item, device):
@@ -61,6 +78,10 @@ class Basic_test:
         self.train_ptr = torch.zeros(self.n_user + 1, dtype=torch.int64, device=self.device)
         torch.cumsum(torch.bincount(self.train_u, minlength=self.n_user), 0, out=self.train_ptr[1:])
         self.with_auc = (self.n_item <= 50_000) if with_auc is None else with_auc
+        # per-user SORTED train items for the fused kernel's mask look-up
+        skey = torch.sort(self.train_u * self.n_item + self.train_i).values
+        self.train_items_sorted = (skey % self.n_item).to(torch.int32).contiguous()
+        self.fused = bool(self.cfg.get("eval_fused", True))
 
     @torch.no_grad()
     def run(self, model, istest=False, group_k=0, all_users=None):
@@ -77,6 +98,28 @@ class Basic_test:
         sums = {m: torch.zeros(len(topks), dtype=torch.float64, device=self.device)
                 for m in ("recall", "precision", "hr", "ndcg")}
         auc_sum = torch.zeros((), dtype=torch.float64, device=self.device)
+
+        def score(users, top):
+            label = _member(key, users[:, None] * self.n_item + top).to(torch.float64)     # get_label
+            n_true = cnt[users].to(torch.float64)
+            for j, k in enumerate(topks):
+                right = label[:, :k].sum(1)
+                sums["recall"][j] += (right / n_true).sum()
+                sums["precision"][j] += right.sum() / k
+                sums["hr"][j] += (right > 0).sum()
+                ideal = torch.cumsum(disc[:k], 0)[(torch.clamp(n_true, max=k) - 1).long()]
+                sums["ndcg"][j] += ((label[:, :k] * disc[:k]).sum(1) / ideal).sum()
+
+        tables = model.forward()[:2] if (self.fused and not self.with_auc and hasattr(model, "forward")) else None
+        if tables is not None and tables[0].shape[1] in FUSED_WIDTHS and tables[0].is_cuda and kmax <= 64:
+            # one propagation, one fused score/mask/top-k pass; metrics in user chunks to bound temporaries
+            top, _ = fused_topk(tables[0], tables[1], all_users, self.train_ptr, self.train_items_sorted, kmax)
+            for lo in range(0, all_users.numel(), 1 << 18):
+                score(all_users[lo:lo + (1 << 18)], top[lo:lo + (1 << 18)])
+            n = float(all_users.numel())
+            out = {m: (v / n).cpu().tolist() for m, v in sums.items()}
+            out["auc"] = [float("nan")]
+            return out
         for users in minibatch(all_users, self.cfg["test_batch"]):
             if users.numel() == 0:
                 continue
@@ -89,15 +132,7 @@ class Basic_test:
             col = self.train_i[start + torch.arange(row.numel(), device=self.device)]
             rating[row, col] = -(1 << 10)
             _, top = torch.topk(rating, k=kmax)
-            label = _member(key, users[:, None] * self.n_item + top).to(torch.float64)     # get_label
-            n_true = cnt[users].to(torch.float64)
-            for j, k in enumerate(topks):
-                right = label[:, :k].sum(1)
-                sums["recall"][j] += (right / n_true).sum()
-                sums["precision"][j] += right.sum() / k
-                sums["hr"][j] += (right > 0).sum()
-                ideal = torch.cumsum(disc[:k], 0)[(torch.clamp(n_true, max=k) - 1).long()]
-                sums["ndcg"][j] += ((label[:, :k] * disc[:k]).sum(1) / ideal).sum()
+            score(users, top)
             if self.with_auc:
                 auc_sum += self._auc(rating, users, key)
         n = float(all_users.numel())

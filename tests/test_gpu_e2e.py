@@ -158,3 +158,46 @@ def test_c2_fused_layer_consistent_with_plain_spmm(c2_graph):
     z = torch.nn.functional.normalize(plain, p=2, dim=1)
     assert float((acc - 0.25 * z).abs().max()) <= 1e-6
     np.testing.assert_allclose(inv.cpu().numpy(), (1.0 / plain.norm(dim=1).clamp_min(1e-12)).cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("D,n_user,n_item,K", [(64, 300, 1000, 20), (256, 130, 515, 20), (16, 70, 33, 10), (192, 64, 200, 5)])
+def test_fused_eval_topk_matches_torch_path(D, n_user, n_item, K):
+    """csrc/eval.hip (score -> mask -> top-K in one pass) against sigmoid(U I^T) + mask + torch.topk."""
+    from tagrec_amd import evaluate as EV
+    gen = torch.Generator(device=DEV).manual_seed(D + n_item)
+    U = torch.randn(n_user, D, device=DEV, generator=gen) * 0.3
+    I = torch.randn(n_item, D, device=DEV, generator=gen) * 0.3
+    mask = torch.rand(n_user, n_item, device=DEV, generator=gen) < 0.15          # train positives
+    mask[5] = False
+    mask[7, : n_item - max(1, K // 2)] = True                                    # fewer than K items left for user 7
+    ptr = torch.zeros(n_user + 1, dtype=torch.int64, device=DEV)
+    torch.cumsum(mask.sum(1), 0, out=ptr[1:])
+    items = torch.nonzero(mask)[:, 1].to(torch.int32).contiguous()               # row-major -> sorted per user
+    users = torch.randperm(n_user, device=DEV, generator=gen)[: n_user - 3]
+    top, val = EV.fused_topk(U, I, users, ptr, items, K)
+    rating = torch.sigmoid(U[users] @ I.t())
+    rating[mask[users]] = -(1 << 10)
+    wv, wi = torch.topk(rating, k=K)
+    for row in range(users.numel()):
+        n_free = int((~mask[users[row]]).sum())
+        k_ok = min(K, n_free)
+        np.testing.assert_allclose(val[row, :k_ok].cpu().numpy(), wv[row, :k_ok].cpu().numpy(), rtol=1e-5, atol=1e-6)
+        got, want = top[row, :k_ok].tolist(), wi[row, :k_ok].tolist()
+        if got != want:                              # only near-ties may differ in order
+            assert sorted(got) == sorted(want) or np.allclose(val[row, :k_ok].cpu(), wv[row, :k_ok].cpu(), atol=1e-6)
+        assert (top[row, k_ok:] == -1).all()         # nothing admitted beyond the un-masked items
+
+
+def test_basic_test_fused_equals_batched_path():
+    ds = T.synth.make_cf_dataset(400, 300, 9000, seed=12)
+    cfg = T.get_config("lightgcn", use_tag=False, dim_layer_list=[64, 64], device=DEV, test_batch=128)
+    torch.manual_seed(3)
+    model = T.LightGCN(ds, config=cfg)
+    opt = T.Adam(model.parameters(), lr=0.01)
+    prod = T.BPR_training_data(ds, config=cfg, seed=1)
+    model.train()
+    T.epoch_training(prod, model.loss, opt, verbose=False)
+    fused = T.Basic_test(ds, config=cfg, with_auc=False).run(model)
+    slow = T.Basic_test(ds, config=dict(cfg, eval_fused=False), with_auc=False).run(model)
+    for k in ("recall", "precision", "hr", "ndcg"):
+        np.testing.assert_allclose(fused[k], slow[k], rtol=1e-9, atol=1e-12, err_msg=k)
