@@ -10,9 +10,11 @@ Adam lr 0.01, train_batch 512 (the reference's default, utility/utils.py:24).  O
 BPR loss, backward, Adam.  Everything is resident in HBM before the timed region; triplets are
 sampled on the device beforehand (the reference also times its sampler separately).
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) the node table, Adam state and
-CSR rows are sharded by row range and every layer all-gathers the shard outputs over RCCL
-(strong scaling of the same graph).
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME graph and batch are split
+over the ranks (strong scaling).  Default `--parallel feature`: every rank holds D/N columns of the
+node table, Adam state and activations plus the whole CSR; only row norms, row dot products and the
+B triplet scores are all-reduced over RCCL.  `--parallel row`: rows are sharded and every layer
+all-gathers the shard outputs (the reference's split_adj_k folds, one per GPU).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused forward layer
 (`spmm_rows_kernel<16, NORM_ACC>`): algorithmic bytes per launch (SURVEY.md 8d:
@@ -48,7 +50,10 @@ def parse():
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--force-shard", action="store_true",
-                    help="run the row-sharded model even with one rank (exercises dist.py + RCCL init on one GPU)")
+                    help="run the sharded model even with one rank (exercises dist.py + RCCL init on one GPU)")
+    ap.add_argument("--parallel", choices=["auto", "feature", "row"], default="auto",
+                    help="multi-GPU sharding of the node table: feature = columns (default when dim %% N == 0 and "
+                         "dim / N >= 8), row = row ranges with an all-gather per layer")
     ap.add_argument("--model", choices=["lightgcn", "ngcf", "tgcn"], default="lightgcn",
                     help="lightgcn = C2 (headline); ngcf = C3 (same graph, D^-1 A + I, MFMA dense layers); "
                          "tgcn = C4 (tripartite, 1M/1M/2M nodes, D=128, k=25; use --steps 3 --warmup 1)")
@@ -209,6 +214,10 @@ def main():
     ne = max(int(50_000_000 * args.scale), 40000)
     D, L, B = args.dim, args.layers, args.batch
     cfg = T.get_config(args.model, use_tag=False, dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B)
+    parallel = args.parallel
+    if parallel == "auto":
+        parallel = "feature" if (D % world == 0 and D // world >= 8) else "row"
+    Dl = D // world if (sharded and parallel == "feature") else D
     if args.model == "ngcf" and world > 1:
         sys.exit("bench.py: the sharded path covers LightGCN (C2/C5); run --model ngcf on one GPU")
 
@@ -224,7 +233,10 @@ def main():
         timed_graph = G
         G.transpose()                      # NGCF: build A^T once, outside the timed region
     else:
-        model = TD.ShardedLightGCN(ds, cfg, rp, col, val, n)
+        if parallel == "feature":
+            model = TD.FeatureShardedLightGCN(ds, cfg, rp, col, val, n)
+        else:
+            model = TD.ShardedLightGCN(ds, cfg, rp, col, val, n)
         timed_graph = model.graph
         del rp, col, val
     opt = T.Adam(model.parameters(), lr=cfg["lr"])
@@ -286,10 +298,13 @@ def main():
 
     # roofline of the dominant kernel: fused forward layer (local rows of this rank)
     dom = "spmm_norm_acc" if args.model == "lightgcn" else "spmm"
+    epi_row_bytes = 8 * D if args.model == "lightgcn" else 0
+    if sharded and parallel == "feature":
+        dom, epi_row_bytes = "spmm_ss", 4                  # Y = A X on D/N columns + one float of row sum-of-squares
     fwd = kernel_ms.get(dom, [])
     n_local_rows = timed_graph.shape[0]
     local_nnz = timed_graph.nnz
-    alg = spmm_bytes(local_nnz, n_local_rows, D, 8 * D if args.model == "lightgcn" else 0)
+    alg = spmm_bytes(local_nnz, n_local_rows, Dl, epi_row_bytes)
     roof = None
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_c2_lightgcn.json")
@@ -301,7 +316,8 @@ def main():
     if fwd:
         ms = sum(fwd) / len(fwd)
         ach = alg / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": f"spmm_rows_kernel<{D // 4}, {'NORM_ACC' if args.model == 'lightgcn' else 'NONE'}> (+ long-row finish)",
+        epi_name = "SS" if dom == "spmm_ss" else ("NORM_ACC" if args.model == "lightgcn" else "NONE")
+        roof = {"bound": "hbm", "kernel": f"spmm_rows_kernel<{Dl // 4}, {epi_name}> (+ long-row finish)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "mean_launch_ms": ms, "launches_timed": len(fwd),
                 "other_kernels_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items() if k != dom}}
@@ -320,7 +336,7 @@ def main():
                "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{'C2' if args.model == 'lightgcn' else 'C3'} {mname} L={L} D={D} users={nu} items={ni} "
                                       f"edges={ne} nnz={nnz} train_batch={B} adam lr=0.01 {cfg['norm_type']} {cfg['mul_loss_func']}",
-                          "train_batch": B, "parallelism": f"row-shard x{world}" if world > 1 else "single"},
+                          "train_batch": B, "parallelism": f"{parallel}-shard x{world}" if sharded else "single"},
                "roofline": roof, "extra": extra}
         if not args.no_cpu and world == 1 and args.model == "lightgcn":
             out["cpu_baseline"] = cpu_baseline(args, nnz)

@@ -78,6 +78,25 @@ int tagrec_spmm_normbwd_f32(const tagrec_graph* g, const float* G_in, const floa
 int tagrec_spmm_axpy_f32(const tagrec_graph* g, const float* G_in, const float* B, float b_scale,
                          float* G_out, int D, void* stream);
 
+/* ---- column-sharded tables (feature sharding over GPUs: every rank holds D/G columns of every row) ---------------
+ * Whatever reduces over a row's columns is split into a local part, an all-reduce done by the caller, and an apply:
+ *   spmm_ss          : Y = A @ X;  ss[r] = sum_c Y[r,c]^2 over the local columns
+ *   row_scale_acc    : acc[r,:] += s * inv[r] * Y[r,:]                          (inv from the all-reduced ss)
+ *   row_dot          : out[r] = inv[r] * s * sum_c X[r,c] dZ[r,c]               (local part of z . (s dZ))
+ *   rownorm_bwd_dot  : dX[r,:] = inv[r] * (s dZ[r,:] - X[r,:] inv[r] dot[r])    (dot all-reduced)
+ *   spmm_normbwd_dot : G_out = A @ G_in + the same expression                   (fused backward layer)
+ *   bpr_dots         : dots[b] = (u.p, u.n, 0.5(|u|^2+|p|^2+|n|^2)) over the local columns */
+int tagrec_spmm_ss_f32(const tagrec_graph* g, const float* X, float* Y, float* ss, int D, void* stream);
+int tagrec_spmm_normbwd_dot_f32(const tagrec_graph* g, const float* G_in, const float* X_raw, const float* inv_norm,
+                                const float* dZ, const float* dot, float d_scale, float* G_out, int D, void* stream);
+int tagrec_row_scale_acc_f32(const float* Y, const float* inv, float s, float* acc, int64_t n_rows, int D, void* stream);
+int tagrec_row_dot_f32(const float* X, const float* inv, const float* dZ, float s, float* out, int64_t n_rows, int D,
+                       void* stream);
+int tagrec_rownorm_bwd_dot_f32(const float* X, const float* inv, const float* dZ, const float* dot, float s, float* dX,
+                               int64_t n_rows, int D, void* stream);
+int tagrec_bpr_dots_f32(const float* U, const float* I, int64_t ld, int D, const float* Ureg, const float* Ireg,
+                        int64_t ldreg, int Dreg, const int64_t* trip, int64_t B, float* dots, void* stream);
+
 /* ---- F.normalize(p=2, dim=1, eps=1e-12) as standalone kernels (ngcf.py:86, tgcn.py:220-222) ----
  * fwd: Z (row stride ldz floats, so it can write one slot of a concat buffer) and inv_norm.
  * bwd: dX = normalize_bwd(X_raw, inv_norm, d_scale * dZ); dZ has row stride lddz; if `accumulate`

@@ -32,6 +32,14 @@ _SIGNATURES = {
     "tagrec_spmm_norm_acc_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p],
     "tagrec_spmm_normbwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p],
     "tagrec_spmm_axpy_f32": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p],
+    "tagrec_spmm_ss_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_spmm_normbwd_dot_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int,
+                                    c_void_p],
+    "tagrec_row_scale_acc_f32": [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p],
+    "tagrec_row_dot_f32": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p],
+    "tagrec_rownorm_bwd_dot_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p],
+    "tagrec_bpr_dots_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                            c_void_p, c_void_p],
     "tagrec_rownorm_fwd_f32": [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
     "tagrec_rownorm_bwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int, c_int64, c_int,
                                c_void_p],

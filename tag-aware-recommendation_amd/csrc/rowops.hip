@@ -60,6 +60,69 @@ __global__ __launch_bounds__(kThreads) void rownorm_bwd_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column-sharded tables (dist.py, feature sharding): each rank holds D/G columns of every row, so everything that
+// reduces over a row's columns is split into "local partial" + all-reduce + "apply".
+//   row_scale_acc : acc[r,:] += s * inv[r] * y[r,:]                         (layer mean, after the norm all-reduce)
+//   row_dot       : out[r]    = inv[r] * s * sum_c x[r,c] dZ[r,c]           (local part of z . (s dZ))
+//   rownorm_bwd_dot: dX[r,:]  = inv[r] * (s dZ[r,:] - x[r,:] inv[r] dot[r]) (dot all-reduced by the caller)
+__global__ __launch_bounds__(kThreads) void row_scale_acc_kernel(const float* __restrict__ Y, const float* __restrict__ inv,
+                                                                 float s, float* __restrict__ acc, int64_t n_rows, int D) {
+  const int64_t total = n_rows * D;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total; i += stride)
+    acc[i] = fmaf(s * inv[i / D], Y[i], acc[i]);
+}
+
+__global__ __launch_bounds__(kThreads) void row_dot_kernel(const float* __restrict__ X, const float* __restrict__ inv,
+                                                           const float* __restrict__ dZ, float s, float* __restrict__ out,
+                                                           int64_t n_rows, int D) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  float d = 0.f;
+  for (int k = lane; k < D; k += kWave) d = fmaf(X[r * D + k], dZ[r * D + k], d);
+  d = wave_sum(d);
+  if (lane == 0) out[r] = inv[r] * s * d;
+}
+
+__global__ __launch_bounds__(kThreads) void rownorm_bwd_dot_kernel(const float* __restrict__ X, const float* __restrict__ inv,
+                                                                   const float* __restrict__ dZ, const float* __restrict__ dot,
+                                                                   float s, float* __restrict__ dX, int64_t n_rows, int D) {
+  const int64_t total = n_rows * D;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / D;
+    const float iv = inv[r];
+    const float dt = iv >= 1e12f ? 0.f : dot[r];
+    dX[i] = iv * (s * dZ[i] - X[i] * iv * dt);
+  }
+}
+
+// local part of the BPR scores and of the L2 term: dots[b] = (u.p, u.n, 0.5(|u|^2+|p|^2+|n|^2)) over this shard's columns
+__global__ __launch_bounds__(kThreads) void bpr_dots_kernel(const float* __restrict__ U, const float* __restrict__ I, int64_t ld,
+                                                            int D, const float* __restrict__ Ur, const float* __restrict__ Ir,
+                                                            int64_t ldr, int Dr, const int64_t* __restrict__ trip, int64_t B,
+                                                            float* __restrict__ dots) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int64_t u = trip[3 * b], p = trip[3 * b + 1], n = trip[3 * b + 2];
+  float pos = 0.f, neg = 0.f, ss = 0.f;
+  for (int k = lane; k < D; k += kWave) {
+    const float uv = U[u * ld + k];
+    pos = fmaf(uv, I[p * ld + k], pos);
+    neg = fmaf(uv, I[n * ld + k], neg);
+  }
+  if (Ur)
+    for (int k = lane; k < Dr; k += kWave) {
+      const float a = Ur[u * ldr + k], bb = Ir[p * ldr + k], cc = Ir[n * ldr + k];
+      ss = fmaf(a, a, fmaf(bb, bb, fmaf(cc, cc, ss)));
+    }
+  pos = wave_sum(pos); neg = wave_sum(neg); ss = wave_sum(ss);
+  if (lane == 0) { dots[3 * b] = pos; dots[3 * b + 1] = neg; dots[3 * b + 2] = 0.5f * ss; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // BPR forward: one wave per triplet.  pos = u.p, neg = u.n; per-triplet loss + sigmoid coefficient;
 // block partial sums (loss, 0.5*||.||^2) in triplet order.
 __device__ __forceinline__ float softplus_torch(float x) {  // F.softplus(beta=1, threshold=20)
@@ -365,6 +428,50 @@ extern "C" int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, in
   const int64_t blocks = (B + 3) / 4;
   bpr_bwd_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
       U, I, ld, D, Ureg, Ireg, ldreg, Dreg, trip, B, coef, g, reg, 1.0f / static_cast<float>(B), dU, dI, dUreg, dIreg);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_row_scale_acc_f32(const float* Y, const float* inv, float s, float* acc, int64_t n_rows, int D,
+                                        void* stream) {
+  TAGREC_REQUIRE(Y && inv && acc && n_rows >= 0 && D >= 1, "row_scale_acc: bad argument");
+  if (n_rows == 0) return TAGREC_OK;
+  int64_t blocks = (n_rows * D + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  row_scale_acc_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(Y, inv, s, acc, n_rows, D);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_row_dot_f32(const float* X, const float* inv, const float* dZ, float s, float* out, int64_t n_rows,
+                                  int D, void* stream) {
+  TAGREC_REQUIRE(X && inv && dZ && out && n_rows >= 0 && D >= 1, "row_dot: bad argument");
+  if (n_rows == 0) return TAGREC_OK;
+  row_dot_kernel<<<static_cast<unsigned>((n_rows + 3) / 4), kThreads, 0, static_cast<hipStream_t>(stream)>>>(X, inv, dZ, s, out,
+                                                                                                             n_rows, D);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_rownorm_bwd_dot_f32(const float* X, const float* inv, const float* dZ, const float* dot, float s,
+                                          float* dX, int64_t n_rows, int D, void* stream) {
+  TAGREC_REQUIRE(X && inv && dZ && dot && dX && n_rows >= 0 && D >= 1, "rownorm_bwd_dot: bad argument");
+  if (n_rows == 0) return TAGREC_OK;
+  int64_t blocks = (n_rows * D + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  rownorm_bwd_dot_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(X, inv, dZ, dot, s, dX,
+                                                                                                          n_rows, D);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_bpr_dots_f32(const float* U, const float* I, int64_t ld, int D, const float* Ureg, const float* Ireg,
+                                   int64_t ldreg, int Dreg, const int64_t* trip, int64_t B, float* dots, void* stream) {
+  TAGREC_REQUIRE(U && I && trip && dots, "bpr_dots: null pointer");
+  TAGREC_REQUIRE(B >= 1 && D >= 1 && ld >= D, "bpr_dots: bad shape");
+  TAGREC_REQUIRE((Ureg == nullptr) == (Ireg == nullptr), "bpr_dots: Ureg/Ireg must both be given or both null");
+  bpr_dots_kernel<<<static_cast<unsigned>((B + 3) / 4), kThreads, 0, static_cast<hipStream_t>(stream)>>>(U, I, ld, D, Ureg, Ireg,
+                                                                                                        ldreg, Dreg, trip, B, dots);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

@@ -28,14 +28,15 @@ constexpr int kLongRow = 1024;
 constexpr int kChunk = 512;
 constexpr int kMaxGenericBlocks = 8;  // scalar kernel keeps D <= 512 in registers
 
-enum Epi { EPI_NONE = 0, EPI_NORM_ACC = 1, EPI_NORMBWD = 2, EPI_AXPY = 3 };
+enum Epi { EPI_NONE = 0, EPI_NORM_ACC = 1, EPI_NORMBWD = 2, EPI_AXPY = 3, EPI_SS = 4, EPI_NORMBWD_DOT = 5 };
 
 struct EpiArgs {
   float* Y;               // [n_rows, D] product (or gradient) out
-  float* inv_norm;        // NORM_ACC: out; NORMBWD: in
+  float* inv_norm;        // NORM_ACC: out; NORMBWD / NORMBWD_DOT: in; SS: out = this shard's sum of squares per row
   float* accum;           // NORM_ACC: accum += s * normalize(y)
   const float* Xraw;      // NORMBWD
-  const float* B;         // NORMBWD: dZ ; AXPY: B
+  const float* B;         // NORMBWD / NORMBWD_DOT: dZ ; AXPY: B
+  const float* dot;       // NORMBWD_DOT: z . (s dZ) per row, summed over ALL column shards by the caller
   float s;
 };
 
@@ -144,11 +145,25 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
     const float4 gz = normalize_bwd<LPR>(xr, e.inv_norm[r], dz);
     if (writer)
       reinterpret_cast<float4*>(e.Y)[off] = make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w);
-  } else {  // EPI_AXPY
+  } else if constexpr (EPI == EPI_AXPY) {
     const float4 b = reinterpret_cast<const float4*>(e.B)[off];
     if (writer)
       reinterpret_cast<float4*>(e.Y)[off] = make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y),
                                                         fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w));
+  } else if constexpr (EPI == EPI_SS) {
+    // column-sharded tables: the row norm needs every shard's columns, so only the local sum of squares is formed
+    const float ss = group_sum<LPR>(f4_dot(acc, acc));
+    if (writer) reinterpret_cast<float4*>(e.Y)[off] = acc;
+    if (lane == 0) e.inv_norm[r] = ss;
+  } else {  // EPI_NORMBWD_DOT: normalize-backward with the row dot product supplied (already summed over shards)
+    const float4 xr = reinterpret_cast<const float4*>(e.Xraw)[off];
+    const float4 dz = reinterpret_cast<const float4*>(e.B)[off];
+    const float inv = e.inv_norm[r];
+    const float dot = inv >= 1e12f ? 0.f : e.dot[r];
+    if (writer)
+      reinterpret_cast<float4*>(e.Y)[off] =
+          make_float4(acc.x + inv * (e.s * dz.x - xr.x * inv * dot), acc.y + inv * (e.s * dz.y - xr.y * inv * dot),
+                      acc.z + inv * (e.s * dz.z - xr.z * inv * dot), acc.w + inv * (e.s * dz.w - xr.w * inv * dot));
   }
 }
 
@@ -278,11 +293,29 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_generic_kern
       const int k = b * kWave + lane;
       if (k < D) e.Y[row + k] = acc[b] + inv * (dz[b] - z[b] * dot);
     }
-  } else {
+  } else if constexpr (EPI == EPI_AXPY) {
 #pragma unroll
     for (int b = 0; b < kMaxGenericBlocks; ++b) {
       const int k = b * kWave + lane;
       if (k < D) e.Y[row + k] = fmaf(e.s, e.B[row + k], acc[b]);
+    }
+  } else if constexpr (EPI == EPI_SS) {
+    float ss = 0.f;
+#pragma unroll
+    for (int b = 0; b < kMaxGenericBlocks; ++b) {
+      const int k = b * kWave + lane;
+      ss = fmaf(acc[b], acc[b], ss);
+      if (k < D) e.Y[row + k] = acc[b];
+    }
+    ss = group_sum<kWave>(ss);
+    if (lane == 0) e.inv_norm[r] = ss;
+  } else {
+    const float inv = e.inv_norm[r];
+    const float dot = inv >= 1e12f ? 0.f : e.dot[r];
+#pragma unroll
+    for (int b = 0; b < kMaxGenericBlocks; ++b) {
+      const int k = b * kWave + lane;
+      if (k < D) e.Y[row + k] = acc[b] + inv * (e.s * e.B[row + k] - e.Xraw[row + k] * inv * dot);
     }
   }
 }
@@ -445,6 +478,7 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
   if (e.B) vec_ok = vec_ok && aligned16(e.B);
   if (vec_ok) {
     switch (D) {
+      case 8: return launch_vec<2, EPI>(g, X, e, s);
       case 16: return launch_vec<4, EPI>(g, X, e, s);
       case 32: return launch_vec<8, EPI>(g, X, e, s);
       case 64: return launch_vec<16, EPI>(g, X, e, s);
@@ -465,14 +499,14 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
 }  // namespace
 
 extern "C" int tagrec_spmm_f32(const tagrec_graph* g, const float* X, float* Y, int D, void* stream) {
-  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, 0.f};
+  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
   return launch_spmm<EPI_NONE>(g, X, e, D, stream, "spmm");
 }
 
 extern "C" int tagrec_spmm_norm_acc_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
                                         float* acc, float acc_scale, int D, void* stream) {
   TAGREC_REQUIRE(inv_norm != nullptr && acc != nullptr, "spmm_norm_acc: null inv_norm or acc");
-  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, acc_scale};
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale};
   return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc");
 }
 
@@ -480,13 +514,28 @@ extern "C" int tagrec_spmm_normbwd_f32(const tagrec_graph* g, const float* G_in,
                                        const float* inv_norm, const float* dZ, float d_scale, float* G_out,
                                        int D, void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr, "spmm_normbwd: null X_raw, inv_norm or dZ");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, d_scale};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale};
   return launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd");
 }
 
 extern "C" int tagrec_spmm_axpy_f32(const tagrec_graph* g, const float* G_in, const float* B, float b_scale,
                                     float* G_out, int D, void* stream) {
   TAGREC_REQUIRE(B != nullptr, "spmm_axpy: null B");
-  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, b_scale};
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy");
+}
+
+extern "C" int tagrec_spmm_ss_f32(const tagrec_graph* g, const float* X, float* Y, float* ss, int D, void* stream) {
+  TAGREC_REQUIRE(ss != nullptr, "spmm_ss: null ss");
+  EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f};
+  return launch_spmm<EPI_SS>(g, X, e, D, stream, "spmm_ss");
+}
+
+extern "C" int tagrec_spmm_normbwd_dot_f32(const tagrec_graph* g, const float* G_in, const float* X_raw,
+                                           const float* inv_norm, const float* dZ, const float* dot, float d_scale,
+                                           float* G_out, int D, void* stream) {
+  TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr && dot != nullptr,
+                 "spmm_normbwd_dot: null X_raw, inv_norm, dZ or dot");
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale};
+  return launch_spmm<EPI_NORMBWD_DOT>(g, G_in, e, D, stream, "spmm_normbwd_dot");
 }

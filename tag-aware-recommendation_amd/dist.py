@@ -1,4 +1,13 @@
-"""Row-sharded LightGCN over the GPUs of one node.
+"""LightGCN over the GPUs of one node: two shardings of the node table.
+
+FEATURE sharding (`FeatureShardedLightGCN`, the default of bench.py --gpus N): rank g holds columns
+[g D/G, (g+1) D/G) of EVERY row (parameters, Adam state, activations) and the whole CSR.  The sparse product is
+independent per column, so propagation needs no exchange of embeddings at all; only what reduces over a row's
+columns crosses GPUs: the row norms (one all-reduce of N floats per layer), the normalise-backward row dot
+products (one all-reduce of L x N floats per step) and the B triplet scores.  About 50 MB per step at C2 instead of
+the 3 GB of embeddings a row partition moves.
+
+ROW sharding (`ShardedLightGCN`): the reference's `split_adj_k` folds on different GPUs, described next.
 
 The reference is single-device; its `split_adj_k` row folds (model/help/adj.py:114-140,
 158-164) compute `cat_g(A[rows_g, :] @ X)` -- exactly the 1-D row partition used here, with
@@ -62,6 +71,36 @@ class HipOps:
                                                   _lib.ptr(trip), B, _lib.ptr(coef), _lib.ptr(g), 1.0, _lib.ptr(dU),
                                                   _lib.ptr(dI), _lib.ptr(dUr), _lib.ptr(dIr), _lib.stream_ptr()),
                    "bpr_bwd")
+
+
+    # -- column-sharded tables -------------------------------------------------------------------
+    def spmm_ss(self, g, x, y, ss):
+        g._call("spmm_ss", _lib.load().tagrec_spmm_ss_f32, g.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(ss), x.shape[1],
+                _lib.stream_ptr())
+
+    def spmm_normbwd_dot(self, g, g_in, x_raw, inv, dz, dot, s, out):
+        g._call("spmm_normbwd_dot", _lib.load().tagrec_spmm_normbwd_dot_f32, g.handle, _lib.ptr(g_in), _lib.ptr(x_raw),
+                _lib.ptr(inv), _lib.ptr(dz), _lib.ptr(dot), float(s), _lib.ptr(out), g_in.shape[1], _lib.stream_ptr())
+
+    def row_scale_acc(self, y, inv, s, acc):
+        _lib.check(_lib.load().tagrec_row_scale_acc_f32(_lib.ptr(y), _lib.ptr(inv), float(s), _lib.ptr(acc), y.shape[0],
+                                                        y.shape[1], _lib.stream_ptr()), "row_scale_acc")
+
+    def row_dot(self, x, inv, dz, s, out):
+        _lib.check(_lib.load().tagrec_row_dot_f32(_lib.ptr(x), _lib.ptr(inv), _lib.ptr(dz), float(s), _lib.ptr(out),
+                                                  x.shape[0], x.shape[1], _lib.stream_ptr()), "row_dot")
+
+    def rownorm_bwd_dot(self, x, inv, dz, dot, s, out):
+        _lib.check(_lib.load().tagrec_rownorm_bwd_dot_f32(_lib.ptr(x), _lib.ptr(inv), _lib.ptr(dz), _lib.ptr(dot), float(s),
+                                                          _lib.ptr(out), x.shape[0], x.shape[1], _lib.stream_ptr()),
+                   "rownorm_bwd_dot")
+
+    def bpr_dots(self, U, I, Ur, Ir, trip):
+        B, D = trip.shape[0], U.shape[1]
+        dots = torch.empty(B, 3, dtype=torch.float32, device=U.device)
+        _lib.check(_lib.load().tagrec_bpr_dots_f32(_lib.ptr(U), _lib.ptr(I), D, D, _lib.ptr(Ur), _lib.ptr(Ir), D, D,
+                                                   _lib.ptr(trip), B, _lib.ptr(dots), _lib.stream_ptr()), "bpr_dots")
+        return dots
 
 
 def shard_rows(n, world):
@@ -211,3 +250,118 @@ class ShardedLightGCN(torch.nn.Module):
 
     def gathered_table(self):
         return self.all_gather(self.table.detach())[:self.n_nodes]
+
+
+# ====================================================================================== feature sharding
+class _FeatureShardedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, model, trip):
+        m = model
+        x0 = table.detach()
+        L, s, n = m.num_layer, 1.0 / (m.num_layer + 1), x0.shape[0]
+        out = x0 * s
+        raws, invs = [], []
+        x = x0
+        for _ in range(L):
+            y = torch.empty_like(x0)
+            ss = torch.empty(n, dtype=torch.float32, device=x0.device)
+            m.ops.spmm_ss(m.graph, x, y, ss)
+            m.all_reduce(ss)                                        # the row norm spans every rank's columns
+            inv = 1.0 / torch.sqrt(ss).clamp_min_(1e-12)
+            m.ops.row_scale_acc(y, inv, s, out)
+            raws.append(y)
+            invs.append(inv)
+            x = y
+        nu, ni, B = m.n_user, m.n_item, trip.shape[0]
+        U, I, Ue, Ie = out[:nu], out[nu:nu + ni], x0[:nu], x0[nu:nu + ni]
+        dots = m.ops.bpr_dots(U, I, Ue, Ie, trip)
+        m.all_reduce(dots)                                          # full-width scores and L2 term
+        xd = dots[:, 1] - dots[:, 0]                                # neg - pos
+        if m.loss_func == "logsigmoid":
+            loss = -torch.nn.functional.logsigmoid(-xd).mean()
+            coef = torch.sigmoid(xd)
+        else:
+            loss = torch.nn.functional.softplus(xd).mean()
+            coef = torch.where(xd > 20.0, torch.ones_like(xd), torch.sigmoid(xd))
+        res = torch.stack([loss, dots[:, 2].sum() / B])
+        ctx.m, ctx.raws, ctx.invs = m, raws, invs
+        ctx.out, ctx.x0, ctx.trip, ctx.coef = out, x0, trip, coef.contiguous()
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        m, raws, invs, out, x0, trip = ctx.m, ctx.raws, ctx.invs, ctx.out, ctx.x0, ctx.trip
+        L, s, n = m.num_layer, 1.0 / (m.num_layer + 1), x0.shape[0]
+        nu, ni = m.n_user, m.n_item
+        g = g.contiguous()
+        d_out = torch.zeros_like(out)
+        U, I, Ue, Ie = out[:nu], out[nu:nu + ni], x0[:nu], x0[nu:nu + ni]
+        m.ops.bpr_bwd(U, I, None, None, trip, ctx.coef, g, d_out[:nu], d_out[nu:nu + ni], None, None)
+        if L == 0:
+            g0 = d_out
+        else:
+            dots = torch.empty(L, n, dtype=torch.float32, device=x0.device)
+            for k in range(L):
+                m.ops.row_dot(raws[k], invs[k], d_out, s, dots[k])
+            m.all_reduce(dots)                                      # every layer's z . (s dZ), one collective
+            gl = torch.empty_like(d_out)
+            m.ops.rownorm_bwd_dot(raws[L - 1], invs[L - 1], d_out, dots[L - 1], s, gl)
+            for k in range(L - 2, -1, -1):
+                gn = torch.empty_like(d_out)
+                m.ops.spmm_normbwd_dot(m.graph, gl, raws[k], invs[k], d_out, dots[k], s, gn)
+                gl = gn
+            g0 = torch.empty_like(d_out)
+            m.ops.spmm_axpy(m.graph, gl, d_out, s, g0)
+        if m.reg != 0:
+            m.ops.bpr_bwd(U, I, Ue, Ie, trip, ctx.coef, g, None, None, g0[:nu], g0[nu:nu + ni])
+        ctx.raws = ctx.invs = ctx.out = None
+        return g0, None, None
+
+
+class FeatureShardedLightGCN(torch.nn.Module):
+    """LightGCN with the embedding COLUMNS sharded over the ranks of the process group (see the module docstring).
+    Same `loss(batch)` / `parameters()` surface as `LightGCN`; every rank must call `loss` with the same batch.
+    Needs a symmetric adjacency (bi_norm) and dim_latent divisible by the number of ranks."""
+
+    def __init__(self, data, config, rowptr, col, val, n_nodes, ops=None, group=None):
+        super().__init__()
+        self.ops = ops if ops is not None else HipOps()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(config["device"])
+        self.num_layer = len(config["dim_layer_list"])
+        self.dim_latent = config["dim_latent"]
+        if self.dim_latent % self.world:
+            raise ValueError(f"feature sharding needs dim_latent ({self.dim_latent}) divisible by the world size ({self.world})")
+        self.dim_local = self.dim_latent // self.world
+        self.reg = config["reg"]
+        self.loss_func = config["mul_loss_func"]
+        self.n_user, self.n_item = data.num["user"], data.num["item"]
+        self.n_nodes = int(n_nodes)
+        self.graph = self.ops.make_graph(rowptr, col, val, (self.n_nodes, self.n_nodes))
+        if hasattr(self.graph, "symmetric"):
+            self.graph.symmetric = True
+        num_list = [self.n_user, self.n_item] + ([data.num["tag"]] if config["use_tag"] else [])
+        assert sum(num_list) == self.n_nodes
+        full = xavier_tables(num_list, self.dim_latent, "cpu")          # same seed on every rank -> same table
+        lo = self.rank * self.dim_local
+        self.table = torch.nn.Parameter(full[:, lo:lo + self.dim_local].contiguous().to(self.device))
+
+    def all_reduce(self, x):
+        if self.world > 1:
+            dist.all_reduce(x, group=self.group)
+        return x
+
+    def loss(self, batch_data):
+        batch_data = batch_data.to(self.device, torch.int64).contiguous()
+        res = _FeatureShardedLoss.apply(self.table, self, batch_data)
+        return res[0], self.reg * res[1]
+
+    def gathered_table(self):
+        """Full [N, D] table on every rank (checkpointing / evaluation)."""
+        if self.world == 1:
+            return self.table.detach().clone()
+        parts = [torch.empty_like(self.table.data) for _ in range(self.world)]
+        dist.all_gather(parts, self.table.data.contiguous(), group=self.group)
+        return torch.cat(parts, dim=1)

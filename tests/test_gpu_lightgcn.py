@@ -265,3 +265,95 @@ def test_sharded_model_with_hip_ops_world1(golden):
         np.testing.assert_allclose([float(v) for v in l2], fx["loss_parts"], rtol=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+def test_feature_sharded_model_with_hip_ops_world1(golden):
+    """dist.FeatureShardedLightGCN with the real HipOps on one rank: the column-sharded kernel chain (spmm_ss ->
+    row_scale_acc -> bpr_dots -> row_dot -> rownorm_bwd_dot -> spmm_normbwd_dot -> spmm_axpy) must reproduce the
+    single-GPU fused model and the reference's fixture; the multi-rank reductions are covered in test_dist_gloo."""
+    import os
+    import torch.distributed as dist
+    from tagrec_amd import dist as TD
+    fx = golden("lightgcn_toy")
+    m = _model(fx)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29573")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        csr = _oracle_csr(fx)
+        cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64, 64], reg=float(fx["reg"]), device=DEV)
+        ds = _ds_from_fixture(fx)
+        sm = TD.FeatureShardedLightGCN(ds, cfg, torch.from_numpy(csr.rowptr).to(DEV), torch.from_numpy(csr.col).to(DEV),
+                                       torch.from_numpy(csr.val).to(DEV), csr.shape[0])
+        with torch.no_grad():
+            sm.table.copy_(m.table)
+        b = torch.from_numpy(fx["batches"][0]).to(DEV)
+        l1, l2 = m.loss(b), sm.loss(b)
+        np.testing.assert_allclose([float(v) for v in l2], [float(v) for v in l1], rtol=1e-6)
+        sum(l1).backward(); sum(l2).backward()
+        np.testing.assert_allclose(sm.table.grad.cpu().numpy(), m.table.grad.cpu().numpy(), rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose([float(v) for v in l2], fx["loss_parts"], rtol=1e-5)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_feature_shard_kernels_compose_to_full_width(golden, G):
+    """The column-sharded kernels on D/G-wide slices (D/G = 32, 16, 8), reduced on the host the way the all-reduces
+    do, equal the full-width fused kernels: forward layer (norm + layer mean), normalise-backward layer, scores."""
+    from tagrec_amd import dist as TD
+    fx = golden("lightgcn_toy")
+    m = _model(fx)
+    g, ops, D = m.graph, TD.HipOps(), 64
+    n = g.shape[0]
+    gen = torch.Generator(device="cpu").manual_seed(G)
+    x = torch.randn(n, D, generator=gen).to(DEV)
+    dz = torch.randn(n, D, generator=gen).to(DEV)
+    gin = torch.randn(n, D, generator=gen).to(DEV)
+    s = 1.0 / 3
+    # full width
+    y_full, inv_full, acc_full = torch.empty_like(x), torch.empty(n, device=DEV), torch.zeros_like(x)
+    g.spmm_norm_acc(x, y_full, inv_full, acc_full, s)
+    out_full = torch.empty_like(x)
+    g.spmm_normbwd(gin, y_full, inv_full, dz, s, out_full)
+    last_full = torch.empty_like(x)
+    ops.rownorm_bwd(y_full, inv_full, dz, s, last_full)
+    # column slices
+    Dl = D // G
+    sl = [slice(k * Dl, (k + 1) * Dl) for k in range(G)]
+    ys, ss = [], torch.zeros(n, device=DEV)
+    for c in sl:
+        y, p = torch.empty(n, Dl, device=DEV), torch.empty(n, device=DEV)
+        ops.spmm_ss(g, x[:, c].contiguous(), y, p)
+        ys.append(y)
+        ss += p
+    inv = 1.0 / torch.sqrt(ss).clamp_min(1e-12)
+    np.testing.assert_allclose(inv.cpu().numpy(), inv_full.cpu().numpy(), rtol=2e-6)
+    dot = torch.zeros(n, device=DEV)
+    for k, c in enumerate(sl):
+        acc = torch.zeros(n, Dl, device=DEV)
+        ops.row_scale_acc(ys[k], inv, s, acc)
+        np.testing.assert_allclose(acc.cpu().numpy(), acc_full[:, c].cpu().numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(ys[k].cpu().numpy(), y_full[:, c].cpu().numpy(), rtol=1e-6, atol=1e-7)
+        p = torch.empty(n, device=DEV)
+        ops.row_dot(ys[k], inv, dz[:, c].contiguous(), s, p)
+        dot += p
+    scale = float(out_full.abs().max())
+    for k, c in enumerate(sl):
+        o = torch.empty(n, Dl, device=DEV)
+        ops.spmm_normbwd_dot(g, gin[:, c].contiguous(), ys[k], inv, dz[:, c].contiguous(), dot, s, o)
+        np.testing.assert_allclose(o.cpu().numpy(), out_full[:, c].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+        o2 = torch.empty(n, Dl, device=DEV)
+        ops.rownorm_bwd_dot(ys[k], inv, dz[:, c].contiguous(), dot, s, o2)
+        np.testing.assert_allclose(o2.cpu().numpy(), last_full[:, c].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    # scores
+    nu, ni = int(fx["n_user"]), int(fx["n_item"])
+    trip = torch.from_numpy(fx["batches"][0]).to(DEV)
+    dots = torch.zeros(trip.shape[0], 3, device=DEV)
+    for c in sl:
+        xs = x[:, c].contiguous()
+        dots += ops.bpr_dots(xs[:nu], xs[nu:nu + ni], xs[:nu], xs[nu:nu + ni], trip)
+    u, p_, n_ = x[:nu][trip[:, 0]], x[nu:nu + ni][trip[:, 1]], x[nu:nu + ni][trip[:, 2]]
+    want = torch.stack([(u * p_).sum(1), (u * n_).sum(1), 0.5 * (u.pow(2).sum(1) + p_.pow(2).sum(1) + n_.pow(2).sum(1))], 1)
+    np.testing.assert_allclose(dots.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
