@@ -3,8 +3,9 @@
 FEATURE sharding (`FeatureShardedLightGCN`, the default of bench.py --gpus N): rank g holds columns
 [g D/G, (g+1) D/G) of EVERY row (parameters, Adam state, activations) and the whole CSR.  The sparse product is
 independent per column, so propagation needs no exchange of embeddings at all; only what reduces over a row's
-columns crosses GPUs: the row norms (one all-reduce of N floats per layer), the normalise-backward row dot
-products (one all-reduce of L x N floats per step) and the B triplet scores.  About 50 MB per step at C2 instead of
+columns crosses GPUs: the row norms (one all-reduce of L x N floats per step -- the chain A^k x runs on the raw
+products, so no layer waits for it), the normalise-backward row dot products (another L x N floats) and the B triplet
+scores.  About 50 MB per step at C2 instead of
 the 3 GB of embeddings a row partition moves.
 
 ROW sharding (`ShardedLightGCN`): the reference's `split_adj_k` folds on different GPUs, described next.
@@ -260,18 +261,20 @@ class _FeatureShardedLoss(torch.autograd.Function):
         x0 = table.detach()
         L, s, n = m.num_layer, 1.0 / (m.num_layer + 1), x0.shape[0]
         out = x0 * s
-        raws, invs = [], []
+        raws = []
         x = x0
-        for _ in range(L):
-            y = torch.empty_like(x0)
-            ss = torch.empty(n, dtype=torch.float32, device=x0.device)
-            m.ops.spmm_ss(m.graph, x, y, ss)
-            m.all_reduce(ss)                                        # the row norm spans every rank's columns
-            inv = 1.0 / torch.sqrt(ss).clamp_min_(1e-12)
-            m.ops.row_scale_acc(y, inv, s, out)
+        ss = torch.empty(max(L, 1), n, dtype=torch.float32, device=x0.device)
+        for k in range(L):                                          # the chain A^k x0 runs on the raw products, so
+            y = torch.empty_like(x0)                                # no layer waits for a collective
+            m.ops.spmm_ss(m.graph, x, y, ss[k])
             raws.append(y)
-            invs.append(inv)
             x = y
+        if L:
+            m.all_reduce(ss)                                        # row norms span every rank's columns: one collective
+        inv_all = 1.0 / torch.sqrt(ss).clamp_min_(1e-12)
+        invs = [inv_all[k] for k in range(L)]
+        for k in range(L):
+            m.ops.row_scale_acc(raws[k], invs[k], s, out)
         nu, ni, B = m.n_user, m.n_item, trip.shape[0]
         U, I, Ue, Ie = out[:nu], out[nu:nu + ni], x0[:nu], x0[nu:nu + ni]
         dots = m.ops.bpr_dots(U, I, Ue, Ie, trip)

@@ -305,7 +305,7 @@ def test_feature_shard_kernels_compose_to_full_width(golden, G):
     from tagrec_amd import dist as TD
     fx = golden("lightgcn_toy")
     m = _model(fx)
-    g, ops, D = m.graph, TD.HipOps(), 64
+    g, ops, D = m._graph(), TD.HipOps(), 64
     n = g.shape[0]
     gen = torch.Generator(device="cpu").manual_seed(G)
     x = torch.randn(n, D, generator=gen).to(DEV)
@@ -335,7 +335,7 @@ def test_feature_shard_kernels_compose_to_full_width(golden, G):
         acc = torch.zeros(n, Dl, device=DEV)
         ops.row_scale_acc(ys[k], inv, s, acc)
         np.testing.assert_allclose(acc.cpu().numpy(), acc_full[:, c].cpu().numpy(), rtol=1e-5, atol=1e-7)
-        np.testing.assert_allclose(ys[k].cpu().numpy(), y_full[:, c].cpu().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(ys[k].cpu().numpy(), y_full[:, c].cpu().numpy(), rtol=1e-5, atol=1e-6)
         p = torch.empty(n, device=DEV)
         ops.row_dot(ys[k], inv, dz[:, c].contiguous(), s, p)
         dot += p
