@@ -47,6 +47,19 @@ struct GraphView {
   const float* val;
 };
 
+// Streamed-once data (indices, values, epilogue operands, outputs) is moved with non-temporal accesses so it does
+// not displace the gathered embedding rows -- the only data with reuse -- from L2 / Infinity Cache.
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+  const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream(float4* p, const float4& a) {
+  __builtin_nontemporal_store(nt_f32x4{a.x, a.y, a.z, a.w}, reinterpret_cast<nt_f32x4*>(p));
+}
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
+
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4_fma(float4& a, float s, const float4& x) {
   a.x = fmaf(s, x.x, a.x); a.y = fmaf(s, x.y, a.y); a.z = fmaf(s, x.z, a.z); a.w = fmaf(s, x.w, a.w);
@@ -72,8 +85,8 @@ __device__ __forceinline__ float4 gather_rows(const GraphView& g, const float* _
     int my_col = 0;
     float my_val = 0.f;
     if (lane < n) {
-      my_col = g.col[base + lane];
-      my_val = g.val[base + lane];
+      my_col = ld_stream(g.col + base + lane);
+      my_val = ld_stream(g.val + base + lane);
     }
     const int groups = (n + NPI - 1) / NPI;
     for (int gi = 0; gi < groups; gi += 4) {
@@ -124,46 +137,46 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
   const bool writer = lane < LPR;
   const int64_t off = r * LPR + (lane % LPR);  // float4 index of this lane's columns
   if constexpr (EPI == EPI_NONE) {
-    if (writer) reinterpret_cast<float4*>(e.Y)[off] = acc;
+    if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
   } else if constexpr (EPI == EPI_NORM_ACC) {
     const float ss = group_sum<LPR>(f4_dot(acc, acc));
     const float den = fmaxf(sqrtf(ss), 1e-12f);
     if (writer) {
-      reinterpret_cast<float4*>(e.Y)[off] = acc;
-      float4 a = reinterpret_cast<const float4*>(e.accum)[off];
+      st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
+      float4 a = ld_stream(reinterpret_cast<const float4*>(e.accum) + off);
       a.x = fmaf(e.s, acc.x / den, a.x);
       a.y = fmaf(e.s, acc.y / den, a.y);
       a.z = fmaf(e.s, acc.z / den, a.z);
       a.w = fmaf(e.s, acc.w / den, a.w);
-      reinterpret_cast<float4*>(e.accum)[off] = a;
+      st_stream(reinterpret_cast<float4*>(e.accum) + off, a);
     }
     if (lane == 0) e.inv_norm[r] = 1.0f / den;
   } else if constexpr (EPI == EPI_NORMBWD) {
-    const float4 xr = reinterpret_cast<const float4*>(e.Xraw)[off];
-    float4 dz = reinterpret_cast<const float4*>(e.B)[off];
+    const float4 xr = ld_stream(reinterpret_cast<const float4*>(e.Xraw) + off);
+    float4 dz = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
     dz.x *= e.s; dz.y *= e.s; dz.z *= e.s; dz.w *= e.s;
     const float4 gz = normalize_bwd<LPR>(xr, e.inv_norm[r], dz);
     if (writer)
-      reinterpret_cast<float4*>(e.Y)[off] = make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w);
+      st_stream(reinterpret_cast<float4*>(e.Y) + off, make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w));
   } else if constexpr (EPI == EPI_AXPY) {
-    const float4 b = reinterpret_cast<const float4*>(e.B)[off];
+    const float4 b = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
     if (writer)
-      reinterpret_cast<float4*>(e.Y)[off] = make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y),
-                                                        fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w));
+      st_stream(reinterpret_cast<float4*>(e.Y) + off, make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y),
+                                                        fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w)));
   } else if constexpr (EPI == EPI_SS) {
     // column-sharded tables: the row norm needs every shard's columns, so only the local sum of squares is formed
     const float ss = group_sum<LPR>(f4_dot(acc, acc));
-    if (writer) reinterpret_cast<float4*>(e.Y)[off] = acc;
+    if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
     if (lane == 0) e.inv_norm[r] = ss;
   } else {  // EPI_NORMBWD_DOT: normalize-backward with the row dot product supplied (already summed over shards)
-    const float4 xr = reinterpret_cast<const float4*>(e.Xraw)[off];
-    const float4 dz = reinterpret_cast<const float4*>(e.B)[off];
+    const float4 xr = ld_stream(reinterpret_cast<const float4*>(e.Xraw) + off);
+    const float4 dz = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
     const float inv = e.inv_norm[r];
     const float dot = inv >= 1e12f ? 0.f : e.dot[r];
     if (writer)
-      reinterpret_cast<float4*>(e.Y)[off] =
-          make_float4(acc.x + inv * (e.s * dz.x - xr.x * inv * dot), acc.y + inv * (e.s * dz.y - xr.y * inv * dot),
-                      acc.z + inv * (e.s * dz.z - xr.z * inv * dot), acc.w + inv * (e.s * dz.w - xr.w * inv * dot));
+      st_stream(reinterpret_cast<float4*>(e.Y) + off,
+                make_float4(acc.x + inv * (e.s * dz.x - xr.x * inv * dot), acc.y + inv * (e.s * dz.y - xr.y * inv * dot),
+                            acc.z + inv * (e.s * dz.z - xr.z * inv * dot), acc.w + inv * (e.s * dz.w - xr.w * inv * dot)));
   }
 }
 
