@@ -113,6 +113,63 @@ def main(only=None):
         if only == "loader":
             return
 
+    def batches_for(ds, n_batch, B, seed):
+        tri = synth.sample_bpr_epoch(ds, seed)
+        return [tri[k * B:(k + 1) * B] for k in range(n_batch)]
+
+    # ------------------------------------------------------------------ N4 siblings: DGCF, DisenGCN (dynamic edge values)
+    def sibling_case(name, ds, model_name, use_tag, n_layer, D, K, T, reg, B, seed):
+        set_cfg(model_name, use_tag=use_tag, dim_layer_list=[D] * n_layer, dim_latent=D, reg=reg, factor_k=K, iterate_k=T)
+        torch.manual_seed(2020)
+        model = {"dgcf": M.DGCF, "disengcn": M.DisenGCN}[model_name](scipy_data(ds))
+        model.train()
+        fx = blocks(ds)
+        fx.update(n_layer=n_layer, D=D, factor_k=K, iterate_k=T, reg=reg, loss_kind=CFG["mul_loss_func"],
+                  norm_type=CFG["norm_type"], use_tag=int(use_tag), lr=0.01)
+        idx = model.norm_adj._indices().numpy()
+        fx["adj_idx"] = idx.copy()
+        for k, v in model.state_dict().items():
+            fx["init." + k] = v.numpy().copy()
+        bs = batches_for(ds, 3, B, seed)
+        fx["batches"] = np.stack(bs)
+        cor = torch.zeros(2, 4, dtype=torch.long)                       # the second half of a DGCF batch; unused by loss()
+        with torch.no_grad():
+            for t, o in enumerate(model.forward()):
+                fx[f"out.{t}"] = o.numpy().copy()
+            if model_name == "dgcf":
+                layer_a = model.forward(out_A=True)                     # per layer: K sparse matrices of routing weights
+                fx["out_A"] = np.stack([np.stack([a._values().numpy() for a in la]) for la in layer_a])
+        lx = model.loss((torch.from_numpy(bs[0]), cor))
+        fx["loss_parts"] = np.array([float(v) for v in lx], dtype=np.float64)
+        model.zero_grad()
+        sum(lx).backward()
+        for k, p in model.named_parameters():
+            fx["grad." + k] = p.grad.numpy().copy()
+        init = {k: v.clone() for k, v in model.state_dict().items()}
+        for n in (1, 3):
+            model.load_state_dict(init)
+            prod = types.SimpleNamespace(reset=lambda: None,
+                                         mini_batch=lambda: iter([(torch.from_numpy(b), cor) for b in bs[:n]]))
+            opt = torch.optim.Adam(model.parameters(), lr=0.01)
+            losses = R["basic_train"].epoch_training(prod, model.loss, opt)
+            fx[f"step{n}.losses"] = np.array(losses, dtype=np.float64)
+            for k, v in model.state_dict().items():
+                fx[f"step{n}." + k] = v.numpy().copy()
+        model.eval()
+        with torch.no_grad():
+            users = torch.arange(0, min(ds.num["user"], 16))
+            fx["predict.users"] = users.numpy()
+            fx["predict.rating"] = model.predict_rating(users).numpy().copy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+        print("wrote", name, {k: v for k, v in fx.items() if np.ndim(v) == 0})
+
+    if only in (None, "siblings"):
+        sibling_case("dgcf_toy", toy, "dgcf", True, 2, 64, 4, 2, 1e-3, 64, 31)
+        sibling_case("dgcf_med", med, "dgcf", False, 1, 32, 2, 3, 0.0, 256, 32)
+        sibling_case("disengcn_toy", toy, "disengcn", True, 2, 64, 4, 2, 1e-3, 64, 33)
+        if only == "siblings":
+            return
+
     # ------------------------------------------------------------------ adjacency (A1-A3)
     fx = blocks(toy)
     for use_tag in (False, True):
@@ -127,10 +184,6 @@ def main(only=None):
     np.savez_compressed(os.path.join(OUT, "adj_toy.npz"), **fx)
 
     # ------------------------------------------------------------------ helpers for model cases
-    def batches_for(ds, n_batch, B, seed):
-        tri = synth.sample_bpr_epoch(ds, seed)
-        return [tri[k * B:(k + 1) * B] for k in range(n_batch)]
-
     def run_steps(model, loss_fn, batches, lr, n_steps):
         """zero_grad / backward / Adam.step exactly as basic_train.epoch_training does,
         via the reference's own epoch_training on a tiny producer object."""
@@ -310,4 +363,4 @@ def main(only=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else None)      # optional: name of a single case ("loader")
+    main(sys.argv[1] if len(sys.argv) > 1 else None)      # optional: a single section ("loader", "siblings")

@@ -217,6 +217,101 @@ def tgcn_transtag_loss(prm, batch, margin, treg):
 
 
 # --------------------------------------------------------------------------- predict / step
+# --------------------------------------------------------------------------- DGCF / DisenGCN
+def _diag_inv_sqrt_rowsum(rows, a, n):
+    """`torch.sparse.sum(adj, dim=1)` -> 1/sqrt, inf -> 0 (model/dgcf.py:96-99); rows without entries get 0
+    (the reference's sparse diagonal has no entry there)."""
+    rs = torch.zeros(n, dtype=a.dtype).index_add_(0, rows, a)
+    d = 1.0 / torch.sqrt(rs)
+    d[torch.isinf(d)] = 0.0
+    return d
+
+
+def dgcf_factor_update(rows, cols, a_factor, ego_split, n):
+    """`DGCF.factor_update` (model/dgcf.py:92-110): D^-1/2 A_f D^-1/2 x with the (detached) routing weights as
+    edge values, then the edge score  normalize(f[head]) . tanh(normalize(x[tail]))."""
+    a = a_factor.detach()
+    d = _diag_inv_sqrt_rowsum(rows, a, n)
+    adj = torch.sparse_coo_tensor(torch.stack([rows, cols]), a, (n, n))
+    f = d[:, None] * ego_split
+    f = torch.sparse.mm(adj, f)
+    f = d[:, None] * f
+    h = F.normalize(f[rows], p=2, dim=1)
+    t = F.normalize(ego_split[cols], p=2, dim=1)
+    return a, f, torch.sum(h * torch.tanh(t), dim=1)
+
+
+def dgcf_forward(tables, rows, cols, n_layer, factor_k, iterate_k, trace=None):
+    """`DGCF.forward` + `iterate_update` (model/dgcf.py:51-90).  rows/cols = `norm_adj._indices()` (int64)."""
+    ego = torch.cat(list(tables), dim=0)
+    n, dk = ego.shape[0], ego.shape[1] // factor_k
+    a_values = torch.ones(factor_k, rows.numel())
+    all_embed = [ego]
+    for _ in range(n_layer):
+        split = torch.split(ego, dk, dim=1)
+        layer_emb, layer_a = [], []
+        for t in range(iterate_k):
+            a_factor = torch.softmax(a_values, dim=0)
+            scores = []
+            for i in range(factor_k):
+                a, f, sc = dgcf_factor_update(rows, cols, a_factor[i], split[i], n)
+                scores.append(sc)
+                if t == iterate_k - 1:
+                    layer_emb.append(f)
+                    layer_a.append(a)
+            a_values = a_values + torch.stack(scores, dim=0)
+        layer_emb = F.normalize(torch.stack(layer_emb), p=2, dim=2)
+        ego = torch.cat(list(layer_emb), dim=1)
+        all_embed.append(ego)
+        if trace is not None:
+            trace.append(torch.stack(layer_a).detach())
+    out = torch.mean(torch.stack(all_embed, dim=1), dim=1)
+    return torch.split(out, [t.shape[0] for t in tables], dim=0)
+
+
+def dgcf_loss(tables, rows, cols, n_layer, factor_k, iterate_k, batch, reg, kind="softplus"):
+    """`DGCF.loss` (model/dgcf.py:115-145): BPR on propagated rows, L2 on the EGO rows; the `cor` half of the
+    batch is unused (the correlation loss is commented out in the reference)."""
+    outs = dgcf_forward(tables, rows, cols, n_layer, factor_k, iterate_k)
+    u, p, ng = batch[:, 0], batch[:, 1], batch[:, 2]
+    loss = mul_loss(outs[0][u], outs[1][p], outs[1][ng], kind)
+    return loss, reg * l2reg_loss(tables[0][u], tables[1][p], tables[1][ng])
+
+
+def disengcn_layer(W, b, rows, cols, x, factor_k, iterate_k, n):
+    """`disengcn.Layer.forward` (model/disengcn.py:23-46): per-factor projection `x (W + b)`, LeakyReLU 0.2,
+    normalise; then `iterate_k` rounds of neighbourhood routing: p = softmax over factors of
+    <new_f[head], f[tail]>, f_i + A(p_i) f_i, normalise (p detached as edge values)."""
+    f = F.normalize(F.leaky_relu(torch.matmul(x, W + b), 0.2), p=2, dim=2)           # [K, n, dk]
+    new_f = f
+    idx = torch.stack([rows, cols])
+    for _ in range(iterate_k):
+        p_uv = torch.softmax(torch.sum(new_f[:, rows] * f[:, cols], dim=2), dim=0)  # [K, nnz]
+        embs = []
+        for i in range(factor_k):
+            adj = torch.sparse_coo_tensor(idx, p_uv[i].detach(), (n, n))
+            embs.append(F.normalize(f[i] + torch.sparse.mm(adj, f[i]), p=2, dim=1))
+        new_f = torch.stack(embs)
+    return torch.cat(list(new_f), dim=1)
+
+
+def disengcn_forward(tables, layers, rows, cols, factor_k, iterate_k):
+    """`DisenGCN.forward` (model/disengcn.py:90-103): only the LAST layer's output is returned (the layer list /
+    mean are commented out in the reference).  layers = [(W [K,D,dk], b [K,1,dk]), ...]."""
+    x = torch.cat(list(tables), dim=0)
+    for W, b in layers:
+        x = disengcn_layer(W, b, rows, cols, x, factor_k, iterate_k, x.shape[0])
+    return torch.split(x, [t.shape[0] for t in tables], dim=0)
+
+
+def disengcn_loss(tables, layers, rows, cols, factor_k, iterate_k, batch, reg, kind="softplus"):
+    """`DisenGCN.loss` (model/disengcn.py:105-131): L2 term on the PROPAGATED rows."""
+    outs = disengcn_forward(tables, layers, rows, cols, factor_k, iterate_k)
+    u, p, ng = batch[:, 0], batch[:, 1], batch[:, 2]
+    ue, pe, ne = outs[0][u], outs[1][p], outs[1][ng]
+    return mul_loss(ue, pe, ne, kind), reg * l2reg_loss(ue, pe, ne)
+
+
 def predict_rating(user_out, item_out, users):
     """`predict_rating` (lightgcn.py:84-89): sigmoid(U_b I^T)."""
     return torch.sigmoid(torch.matmul(user_out[users], item_out.t()))

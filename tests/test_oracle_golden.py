@@ -128,6 +128,69 @@ def test_ngcf_oracle(golden, name):
         np.testing.assert_allclose(p.detach().numpy(), fx[f"step3.mat.{k}"], rtol=1e-4, atol=5e-5)
 
 
+# ------------------------------------------------------------------ N4 siblings: DGCF, DisenGCN
+def _edge_index(fx):
+    """`norm_adj._indices()` of the "plain" adjacency, rebuilt from the interaction blocks: row-major order."""
+    csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, int(fx["use_tag"]))), "plain")
+    rows, cols = csr.rows(), csr.col.astype(np.int64)
+    assert np.array_equal(np.stack([rows, cols]), fx["adj_idx"])          # same entry order as the reference's tensor
+    return torch.from_numpy(rows), torch.from_numpy(cols)
+
+
+@pytest.mark.parametrize("name", ["dgcf_toy", "dgcf_med"])
+def test_dgcf_oracle(golden, name):
+    fx = golden(name)
+    rows, cols = _edge_index(fx)
+    L, K, T = int(fx["n_layer"]), int(fx["factor_k"]), int(fx["iterate_k"])
+    tabs = [t.requires_grad_() for t in _tables(fx)]
+    trace = []
+    outs = om.dgcf_forward(tabs, rows, cols, L, K, T, trace)
+    for t, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), fx[f"out.{t}"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(torch.stack(trace).numpy(), fx["out_A"], rtol=1e-5, atol=1e-7)
+    batch = torch.from_numpy(fx["batches"][0])
+    loss, reg = om.dgcf_loss(tabs, rows, cols, L, K, T, batch, float(fx["reg"]), str(fx["loss_kind"]))
+    np.testing.assert_allclose([float(loss), float(reg)], fx["loss_parts"], rtol=1e-6)
+    (loss + reg).backward()
+    for t, p in enumerate(tabs):
+        np.testing.assert_allclose(p.grad.numpy(), fx[f"grad.embed.{t}"], rtol=1e-5, atol=1e-9)
+    # three Adam steps
+    tabs = [t.requires_grad_() for t in _tables(fx)]
+    opt = torch.optim.Adam(tabs, lr=float(fx["lr"]))
+    fn = lambda b: om.dgcf_loss(tabs, rows, cols, L, K, T, b, float(fx["reg"]), str(fx["loss_kind"]))
+    totals, _ = om.adam_epoch(tabs, fn, [torch.from_numpy(b) for b in fx["batches"][:3]], opt)
+    np.testing.assert_allclose(totals, fx["step3.losses"], rtol=1e-5)
+    for t, p in enumerate(tabs):
+        # Adam amplifies last-bit differences of near-zero gradients (see test_lightgcn_adam_steps)
+        np.testing.assert_allclose(p.detach().numpy(), fx[f"step3.embed.{t}"], rtol=1e-5, atol=2e-4)
+
+
+def _disen_layers(fx, prefix="init."):
+    n = len([k for k in fx if k.startswith(prefix + "layer.") and k.endswith(".W")])
+    return [(torch.from_numpy(fx[f"{prefix}layer.{k}.W"].copy()), torch.from_numpy(fx[f"{prefix}layer.{k}.b"].copy()))
+            for k in range(n)]
+
+
+def test_disengcn_oracle(golden):
+    fx = golden("disengcn_toy")
+    rows, cols = _edge_index(fx)
+    K, T = int(fx["factor_k"]), int(fx["iterate_k"])
+    tabs = [t.requires_grad_() for t in _tables(fx)]
+    layers = [(W.requires_grad_(), b.requires_grad_()) for W, b in _disen_layers(fx)]
+    outs = om.disengcn_forward(tabs, layers, rows, cols, K, T)
+    for t, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), fx[f"out.{t}"], rtol=1e-5, atol=1e-7)
+    batch = torch.from_numpy(fx["batches"][0])
+    loss, reg = om.disengcn_loss(tabs, layers, rows, cols, K, T, batch, float(fx["reg"]), str(fx["loss_kind"]))
+    np.testing.assert_allclose([float(loss), float(reg)], fx["loss_parts"], rtol=1e-6)
+    (loss + reg).backward()
+    for t, p in enumerate(tabs):
+        np.testing.assert_allclose(p.grad.numpy(), fx[f"grad.embed.{t}"], rtol=1e-4, atol=1e-9)
+    for k, (W, b) in enumerate(layers):
+        np.testing.assert_allclose(W.grad.numpy(), fx[f"grad.layer.{k}.W"], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(b.grad.numpy(), fx[f"grad.layer.{k}.b"], rtol=1e-4, atol=1e-9)
+
+
 def test_predict_rating(golden):
     fx = golden("lightgcn_toy")
     A, L = _adj(fx), len(fx["layers"])
