@@ -127,6 +127,35 @@ int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, int D,
                        const int64_t* trip, int64_t B, const float* coef, const float* g, float reg,
                        float* dU, float* dI, float* dUreg, float* dIreg, void* stream);
 
+/* ---- N4: propagation with dynamic per-factor edge weights (DGCF model/dgcf.py:70-110, DisenGCN model/disengcn.py:23-46) --
+ * The graph handle supplies the STRUCTURE (rowptr / colidx; its values are not read).  K factors own the column
+ * slices [k D/K, (k+1) D/K) of an embedding row (torch.split / torch.cat along dim 1 in the reference).  Per-entry
+ * data is factor-interleaved [nnz, K] in CSR entry order; per-node data [N, K].  D in {32,64,128,256}, K in {1,2,4,8},
+ * D/K a multiple of 4.
+ *   route_softmax      : w[j, :] = softmax(logits[j, :])                      (torch.softmax(A_values, dim=0))
+ *   route_rowsum_rsqrt : d[r, k] = 1 / sqrt(sum_j w[j, k] over row r), inf -> 0  (dgcf.py:95-99)
+ *   route_permute      : wt[j, :] = w[perm[j], :]                              (weights in the transposed matrix's order)
+ *   route_spmm         : y[r, slice k] = post[r,k] * sum_j w[j,k] X[col_j, slice k] + self[r] + b_scale * B[r];
+ *                        Y = y, Yn = y / max(||y slice||, 1e-12), inv[r,k] = 1 / max(||y slice||, 1e-12)
+ *                        (post / self / B / Y / Yn / inv may each be NULL)
+ *   route_score        : logits[j, k] (+)= < H[row_j, slice k], T[col_j, slice k] >
+ *   slice_scale        : Y[r, slice k] = scale[r, k] * X[r, slice k]
+ *   slice_norm_fwd     : Y = X / max(||X slice||, 1e-12) per slice (then tanh if apply_tanh); inv (may be NULL) as above
+ *   slice_norm_bwd     : gradient of slice_norm_fwd (without tanh) given X_raw, inv and dZ */
+int tagrec_route_softmax_f32(const float* logits, float* w, int64_t nnz, int K, void* stream);
+int tagrec_route_rowsum_rsqrt_f32(const tagrec_graph* g, const float* w, int K, float* d, void* stream);
+int tagrec_route_permute_f32(const float* w, const int32_t* perm, float* wt, int64_t nnz, int K, void* stream);
+int tagrec_route_spmm_f32(const tagrec_graph* g, const float* W, int K, const float* X, const float* post,
+                          const float* self, const float* B, float b_scale, float* Y, float* Yn, float* inv,
+                          int D, void* stream);
+int tagrec_route_score_f32(const tagrec_graph* g, const float* H, const float* T, float* logits, int K,
+                           int accumulate, int D, void* stream);
+int tagrec_slice_scale_f32(const float* X, const float* scale, float* Y, int64_t n_rows, int D, int K, void* stream);
+int tagrec_slice_norm_fwd_f32(const float* X, float* Y, float* inv, int64_t n_rows, int D, int K, int apply_tanh,
+                              void* stream);
+int tagrec_slice_norm_bwd_f32(const float* X_raw, const float* inv, const float* dZ, float* dX, int64_t n_rows, int D,
+                              int K, void* stream);
+
 /* ---- evaluation: sigmoid(U_b I^T) -> mask train positives -> top-K, fused (lightgcn.py:84-89, basic_test.py:36-50) --
  * U / I: propagated user / item tables, row-major [*, D].  users: int64 [n_users] ids to score.  train_ptr int64
  * [n_user_total + 1] / train_items int32: each user's train items, sorted (the rows basic_test.py:47 overwrites with

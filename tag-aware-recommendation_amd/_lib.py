@@ -64,6 +64,15 @@ _SIGNATURES = {
     "tagrec_tgcn_fuse_wf_workspace": [c_int, c_int],
     "tagrec_tgcn_fuse_wf_result": [c_int, c_int],
     "tagrec_tgcn_fuse_wf_f32": [c_void_p] * 10 + [c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p],
+    "tagrec_route_softmax_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "tagrec_route_rowsum_rsqrt_f32": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "tagrec_route_permute_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "tagrec_route_spmm_f32": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                              c_void_p, c_int, c_void_p],
+    "tagrec_route_score_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tagrec_slice_scale_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
+    "tagrec_slice_norm_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
+    "tagrec_slice_norm_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "tagrec_eval_topk_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                              c_void_p, c_void_p],
     "tagrec_sample_negative_i64": [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, ctypes.c_uint64, c_void_p, c_void_p],

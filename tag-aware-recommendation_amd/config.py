@@ -24,6 +24,9 @@ _PER_MODEL = {
     "lightgcn": {"mul_loss_func": "softplus", "norm_type": "bi_norm", "cor_batch": 100},
     "tgcn": {"dim_weight": 10, "dim_atten": 32, "num_bit_conv": 32, "num_vec_conv": 8, "margin": 1,
              "transtag_batch": 512, "neighbor_k": 25, "transtag_reg": 0.0001, "mul_loss_func": "logsigmoid"},
+    # utility/config.py:14-30
+    "dgcf": {"mul_loss_func": "softplus", "norm_type": "plain", "factor_k": 4, "iterate_k": 2, "cor_batch": 100},
+    "disengcn": {"mul_loss_func": "softplus", "norm_type": "plain", "factor_k": 4, "iterate_k": 2, "cor_batch": 100},
 }
 
 

@@ -1,0 +1,46 @@
+// The CSR handle behind `tagrec_graph*` and the device-side views of it, shared by the kernels that walk
+// adjacency rows (spmm.hip, routing.hip).
+#pragma once
+
+#include "common.h"
+
+// Borrowed CSR arrays + the long-row work list built once by tagrec_graph_create (spmm.hip).
+struct tagrec_graph {
+  int64_t n_rows, n_cols, nnz;
+  const int64_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  int64_t n_long, n_chunks;
+  int32_t* long_rows;
+  int32_t* long_base;
+  int2* chunk_desc;
+  mutable float* slab;        // n_chunks x D partial sums, grown on demand
+  mutable size_t slab_floats;
+};
+
+namespace tagrec {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kLongRow = 1024;   // rows with more stored entries are cut into chunks
+constexpr int kChunk = 512;      // entries per chunk (one wavefront each)
+
+struct GraphView {
+  int64_t n_rows;
+  const int64_t* rowptr;
+  const int32_t* col;
+  const float* val;
+};
+
+// The FIRST `chunk_blocks` blocks of a row-walking launch take the long-row chunks.
+struct LongView {
+  const int32_t* long_rows;
+  const int2* chunk_desc;   // (index into long_rows, chunk number)
+  int64_t n_chunks;
+  float* slab;              // [n_chunks, width] partial results
+  unsigned chunk_blocks;
+};
+
+// Grow g->slab to n_chunks x width floats.
+int ensure_slab(const tagrec_graph* g, int width);
+
+}  // namespace tagrec

@@ -20,12 +20,10 @@
 #include <new>
 
 #include "common.h"
+#include "graph.h"
 
 namespace tagrec {
 
-constexpr int kWavesPerBlock = 4;
-constexpr int kLongRow = 1024;
-constexpr int kChunk = 512;
 constexpr int kMaxGenericBlocks = 8;  // scalar kernel keeps D <= 512 in registers
 
 enum Epi { EPI_NONE = 0, EPI_NORM_ACC = 1, EPI_NORMBWD = 2, EPI_AXPY = 3, EPI_SS = 4, EPI_NORMBWD_DOT = 5 };
@@ -38,13 +36,6 @@ struct EpiArgs {
   const float* B;         // NORMBWD / NORMBWD_DOT: dZ ; AXPY: B
   const float* dot;       // NORMBWD_DOT: z . (s dZ) per row, summed over ALL column shards by the caller
   float s;
-};
-
-struct GraphView {
-  int64_t n_rows;
-  const int64_t* rowptr;
-  const int32_t* col;
-  const float* val;
 };
 
 // Streamed-once data (indices, values, epilogue operands, outputs) is moved with non-temporal accesses so it does
@@ -183,14 +174,6 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
 // ---- main kernel: one wave per short row; the FIRST blocks of the grid take the long-row chunks ----
 // (one wave per kChunk entries, partial sums to a slab) so the heavy items start first and the same
 // launch covers every stored entry of the matrix.
-struct LongView {
-  const int32_t* long_rows;
-  const int2* chunk_desc;
-  int64_t n_chunks;
-  float* slab;
-  unsigned chunk_blocks;
-};
-
 template <int LPR, int EPI>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(GraphView g, const float* __restrict__ X,
                                                                             EpiArgs e, LongView lv) {
@@ -363,19 +346,6 @@ __global__ void fill_long_kernel(const int64_t* __restrict__ rowptr, int64_t n_r
 
 using namespace tagrec;
 
-struct tagrec_graph {
-  int64_t n_rows, n_cols, nnz;
-  const int64_t* rowptr;
-  const int32_t* col;
-  const float* val;
-  int64_t n_long, n_chunks;
-  int32_t* long_rows;
-  int32_t* long_base;
-  int2* chunk_desc;
-  mutable float* slab;        // n_chunks x D partial sums, grown on demand
-  mutable size_t slab_floats;
-};
-
 extern "C" int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz,
                                    const int64_t* rowptr, const int32_t* colidx, const float* vals, void* stream) {
   TAGREC_REQUIRE(out != nullptr, "graph_create: out is null");
@@ -442,9 +412,7 @@ extern "C" int tagrec_graph_info(const tagrec_graph* g, int64_t* n_rows, int64_t
   return TAGREC_OK;
 }
 
-namespace {
-
-int ensure_slab(const tagrec_graph* g, int D) {
+int tagrec::ensure_slab(const tagrec_graph* g, int D) {
   const size_t need = static_cast<size_t>(g->n_chunks) * D;
   if (need <= g->slab_floats) return TAGREC_OK;
   if (g->slab) TAGREC_HIP(hipFree(g->slab));
@@ -454,6 +422,8 @@ int ensure_slab(const tagrec_graph* g, int D) {
   g->slab_floats = need;
   return TAGREC_OK;
 }
+
+namespace {
 
 template <int LPR, int EPI>
 int launch_vec(const tagrec_graph* g, const float* X, const EpiArgs& e, hipStream_t s) {

@@ -93,6 +93,56 @@ class BPR_training_data(Abstract_training_data):
         return data[perm].contiguous()
 
 
+class DGCF_training_data(Abstract_training_data):
+    """The per-batch sampler DGCF / DisenGCN train with (train_data/bpr_training_data.py:47-83, utils.py:58-80):
+    every mini-batch draws `train_batch` users (without replacement when there are more users than that), one of
+    the user's train items and one rejected-negative item, plus `cor_batch` random ids per node type (the unused
+    `cor` half).  E // B + 1 batches per epoch; `reset()` does nothing.  Drawn on the device; statistical parity
+    only (the reference draws from Python's and numpy's global generators)."""
+
+    def __init__(self, data, args=None, config=None, seed=None):
+        super().__init__(args, config)
+        cfg = config if config is not None else _GLOBAL_CFG
+        self.cor_batch = cfg.get("cor_batch", 100)
+        self.use_tag = cfg["use_tag"]
+        self.num_item, self.num_user, self.num_tag = data.num["item"], data.num["user"], data.num.get("tag", 0)
+        pos = data.edge_index["train"]
+        pos = (pos if isinstance(pos, torch.Tensor) else torch.from_numpy(np.asarray(pos))).to(self.device, torch.int64)
+        self._pos = _Positives(pos[:, 0], pos[:, 1], self.num_user, self.num_item)
+        deg = self._pos.rowptr[1:] - self._pos.rowptr[:-1]
+        self._users = torch.nonzero(deg > 0).flatten()                 # keys of user_items['train']
+        self.tot_inter = pos.shape[0] // self.batch_size + 1
+        self._seed = int(cfg["seed"] if seed is None else seed)
+        self._draws = 0
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(self._seed)
+
+    def mini_sample(self):
+        B, nu = self.batch_size, self._users.numel()
+        if nu > B:
+            pick = torch.randperm(nu, device=self.device, generator=self._gen)[:B]
+        else:
+            pick = torch.randint(0, nu, (B,), device=self.device, generator=self._gen)
+        u = self._users[pick]
+        lo, hi = self._pos.rowptr[u], self._pos.rowptr[u + 1]
+        r = torch.rand(B, device=self.device, generator=self._gen)
+        at = torch.minimum(lo + (r * (hi - lo)).long(), hi - 1)
+        pos_i = self._pos.cols[at].long()
+        neg_i = self._pos.sample(u, (self._seed << 20) + self._draws)
+        self._draws += 1
+        cor = [torch.randperm(n, device=self.device, generator=self._gen)[:self.cor_batch]
+               for n in ([self.num_user, self.num_item] + ([self.num_tag] if self.use_tag else []))]
+        k = min(c.numel() for c in cor)
+        return torch.stack([u, pos_i, neg_i], dim=1), torch.stack([c[:k] for c in cor])
+
+    def reset(self):
+        pass
+
+    def mini_batch(self):
+        for _ in range(self.tot_inter):
+            yield self.mini_sample()
+
+
 class Fixed_training_data(Abstract_training_data):
     """Replays given per-epoch triplet arrays (parity runs against the CPU oracle)."""
 
