@@ -54,9 +54,10 @@ def parse():
     ap.add_argument("--parallel", choices=["auto", "feature", "row"], default="auto",
                     help="multi-GPU sharding of the node table: feature = columns (default when dim %% N == 0 and "
                          "dim / N >= 8), row = row ranges with an all-gather per layer")
-    ap.add_argument("--model", choices=["lightgcn", "ngcf", "tgcn"], default="lightgcn",
+    ap.add_argument("--model", choices=["lightgcn", "ngcf", "tgcn", "dgcf", "disengcn"], default="lightgcn",
                     help="lightgcn = C2 (headline); ngcf = C3 (same graph, D^-1 A + I, MFMA dense layers); "
-                         "tgcn = C4 (tripartite, 1M/1M/2M nodes, D=128, k=25; use --steps 3 --warmup 1)")
+                         "tgcn = C4 (tripartite, 1M/1M/2M nodes, D=128, k=25; use --steps 3 --warmup 1); "
+                         "dgcf / disengcn = the C2 graph with dynamic per-factor edge weights (4 factors, 2 routing iterations)")
     return ap.parse_args()
 
 
@@ -223,15 +224,18 @@ def main():
 
     t0 = time.perf_counter()
     ds = T.synth.make_bipartite_device(nu, ni, ne, seed=1, device=dev)
+    if args.model == "disengcn":
+        ds.num["tag"] = 0                   # the reference's DisenGCN always carries a tag table; empty here
     e = ds.edge_index["train"]
     rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], nu, ni, cfg["norm_type"])
     nnz = int(rp[-1])
     torch.manual_seed(cfg["seed"])
     if not sharded:
-        G = T.Graph(rp, col, val, (n, n), symmetric=(cfg["norm_type"] == "bi_norm"))
-        model = (T.LightGCN if args.model == "lightgcn" else T.NGCF)(ds, config=cfg, graph=G)
+        G = T.Graph(rp, col, val, (n, n), symmetric=(cfg["norm_type"] in ("bi_norm", "plain")))
+        model = {"lightgcn": T.LightGCN, "ngcf": T.NGCF, "dgcf": T.DGCF, "disengcn": T.DisenGCN}[args.model](ds, config=cfg, graph=G)
         timed_graph = G
-        G.transpose()                      # NGCF: build A^T once, outside the timed region
+        if not routed:
+            G.transpose()                  # NGCF: build A^T once, outside the timed region
     else:
         if parallel == "feature":
             model = TD.FeatureShardedLightGCN(ds, cfg, rp, col, val, n)
@@ -299,12 +303,22 @@ def main():
     # roofline of the dominant kernel: fused forward layer (local rows of this rank)
     dom = "spmm_norm_acc" if args.model == "lightgcn" else "spmm"
     epi_row_bytes = 8 * D if args.model == "lightgcn" else 0
+    KF = cfg.get("factor_k", 1)
+    if routed:
+        dom = "route_spmm"
     if sharded and parallel == "feature":
         dom, epi_row_bytes = "spmm_ss", 4                  # Y = A X on D/N columns + one float of row sum-of-squares
     fwd = kernel_ms.get(dom, [])
     n_local_rows = timed_graph.shape[0]
     local_nnz = timed_graph.nnz
     alg = spmm_bytes(local_nnz, n_local_rows, Dl, epi_row_bytes)
+    if routed:
+        # routed product: per stored entry col + K weights + one D-wide row; per row rowptr + the outputs it writes
+        # (forward: raw + normalised + K inverse norms; backward: one); mean over the launches of a step
+        n_fwd, n_bwd = L * cfg["iterate_k"], L
+        per_row = (n_fwd * (8 + 8 * D + 8 * KF + (4 * D if args.model == "disengcn" else 0)) +
+                   n_bwd * (8 + 4 * D + (4 * D if args.model == "disengcn" else 4 * KF))) / (n_fwd + n_bwd)
+        alg = local_nnz * (4 + 4 * KF + 4 * D) + n_local_rows * per_row
     roof = None
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_c2_lightgcn.json")
@@ -317,24 +331,28 @@ def main():
         ms = sum(fwd) / len(fwd)
         ach = alg / (ms * 1e-3) / 1e9
         epi_name = "SS" if dom == "spmm_ss" else ("NORM_ACC" if args.model == "lightgcn" else "NONE")
-        roof = {"bound": "hbm", "kernel": f"spmm_rows_kernel<{Dl // 4}, {epi_name}> (+ long-row finish)",
+        kname = f"route_spmm_kernel<{D // 4}, {KF}>" if routed else f"spmm_rows_kernel<{Dl // 4}, {epi_name}>"
+        roof = {"bound": "hbm", "kernel": kname + " (+ long-row finish)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "mean_launch_ms": ms, "launches_timed": len(fwd),
                 "other_kernels_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items() if k != dom}}
         if args.model == "lightgcn":
             step_bytes = 2 * L * spmm_bytes(nnz, n, D, 0) + L * n * 20 * D + 28 * n * D
             extra["step_algorithmic_GBps"] = step_bytes / (dt / K) / 1e9 / world
+        elif routed:
+            extra["routing"] = {"factor_k": KF, "iterate_k": cfg["iterate_k"],
+                                "routed_products_per_step": len(fwd) // K, "score_passes_per_step": len(kernel_ms.get("route_score", [])) // K}
         else:
             extra["dense_gflop_per_step"] = L * 3 * 2 * 2 * n * D * D / 1e9      # fwd + recompute/dA + dW, two matrices each
 
     if rank == 0:
-        mname = "LightGCN" if args.model == "lightgcn" else "NGCF"
+        mname = {"lightgcn": "LightGCN", "ngcf": "NGCF", "dgcf": "DGCF", "disengcn": "DisenGCN"}[args.model]
         size = "1M users x 1M items x 50M edges" if args.scale == 1.0 else f"{nu} users x {ni} items x {ne} edges"
         out = {"metric": f"BPR triplets/sec, {mname} {L}-layer dim{D}, {size}",
                "value": K * B / dt, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": dt / K * 1e3, "higher_is_better": True,
                "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{'C2' if args.model == 'lightgcn' else 'C3'} {mname} L={L} D={D} users={nu} items={ni} "
+               "config": {"workload": f"{ {'lightgcn': 'C2', 'ngcf': 'C3'}.get(args.model, 'C2-graph') } {mname} L={L} D={D} users={nu} items={ni} "
                                       f"edges={ne} nnz={nnz} train_batch={B} adam lr=0.01 {cfg['norm_type']} {cfg['mul_loss_func']}",
                           "train_batch": B, "parallelism": f"{parallel}-shard x{world}" if sharded else "single"},
                "roofline": roof, "extra": extra}

@@ -252,7 +252,10 @@ def test_disengcn_golden(golden):
         sd = m.state_dict()
         for key in sd:
             got, want = sd[key].cpu().numpy(), fx[f"step{n_steps}.{key}"]
-            assert np.abs(got - want).max() <= 3e-4, key
+            # Adam turns a gradient g into lr * g / (|g| + 1e-8): entries whose gradient is ~1e-8 move by a visible
+            # fraction of lr on a last-bit difference, so bound the bulk tightly and the outliers by lr / 10
+            assert np.mean(np.abs(got - want) <= 2e-5) >= 0.99, key
+            assert np.abs(got - want).max() <= 1e-3, key
 
 
 def test_dgcf_training_data_producer():
