@@ -219,8 +219,9 @@ def main():
     if parallel == "auto":
         parallel = "feature" if (D % world == 0 and D // world >= 8) else "row"
     Dl = D // world if (sharded and parallel == "feature") else D
-    if args.model == "ngcf" and world > 1:
-        sys.exit("bench.py: the sharded path covers LightGCN (C2/C5); run --model ngcf on one GPU")
+    if args.model != "lightgcn" and world > 1:
+        sys.exit(f"bench.py: the sharded path covers LightGCN (C2/C5); run --model {args.model} on one GPU")
+    routed = args.model in ("dgcf", "disengcn")
 
     t0 = time.perf_counter()
     ds = T.synth.make_bipartite_device(nu, ni, ne, seed=1, device=dev)
