@@ -117,6 +117,14 @@ def main(only=None):
         tri = synth.sample_bpr_epoch(ds, seed)
         return [tri[k * B:(k + 1) * B] for k in range(n_batch)]
 
+    def run_steps(model, loss_fn, batches, lr, n_steps):
+        """zero_grad / backward / Adam.step exactly as basic_train.epoch_training does,
+        via the reference's own epoch_training on a tiny producer object."""
+        prod = types.SimpleNamespace(reset=lambda: None,
+                                     mini_batch=lambda: iter([torch.from_numpy(b) for b in batches[:n_steps]]))
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        return R["basic_train"].epoch_training(prod, loss_fn, opt)
+
     # ------------------------------------------------------------------ N4 siblings: DGCF, DisenGCN (dynamic edge values)
     def sibling_case(name, ds, model_name, use_tag, n_layer, D, K, T, reg, B, seed):
         set_cfg(model_name, use_tag=use_tag, dim_layer_list=[D] * n_layer, dim_latent=D, reg=reg, factor_k=K, iterate_k=T)
@@ -167,6 +175,80 @@ def main(only=None):
         sibling_case("dgcf_toy", toy, "dgcf", True, 2, 64, 4, 2, 1e-3, 64, 31)
         sibling_case("dgcf_med", med, "dgcf", False, 1, 32, 2, 3, 0.0, 256, 32)
         sibling_case("disengcn_toy", toy, "disengcn", True, 2, 64, 4, 2, 1e-3, 64, 33)
+        # KGAT: the data object carries the duplicate (user, tag) / (item, tag) entries TGCN_load's COO matrices have
+        # (one per (u, i, t) assignment, data/tgcn_load.py:21-22), which torch.sparse.softmax sums before normalising
+        import data as ref_data
+
+        def kgat_data(ds, layout):
+            o = scipy_data(ds)
+            for nm in ("ut_adj", "it_adj"):
+                c = getattr(ds, nm)
+                cnt = c.data.astype(np.int64)
+                setattr(o, nm, sp.coo_matrix((np.ones(int(cnt.sum()), np.float32), (np.repeat(c.row, cnt), np.repeat(c.col, cnt))),
+                                             shape=c.shape))
+            wired = ref_data.TGCN_load.create_edge(o)                      # dict k -> [2, E] (what com.py:78-79 passes)
+            o.create_edge = (lambda: wired) if layout == "wired" else (lambda: {k: v.T.copy() for k, v in wired.items()})
+            return o
+
+        def kgat_case(name, ds, agg_type, layers, D, Dr, reg, B, seed, layout="pairs"):
+            set_cfg("kgat", use_tag=True, dim_layer_list=list(layers), dim_latent=D, dim_relation=Dr, reg=reg, agg_type=agg_type)
+            torch.manual_seed(2020)
+            model = M.KGAT(kgat_data(ds, layout))
+            model.train()
+            fx = blocks(ds)
+            fx.update(layers=np.array(layers), D=D, dim_relation=Dr, reg=reg, agg_type=agg_type, lr=0.01,
+                      transe_reg=CFG["transe_reg"], cor_reg=CFG["cor_reg"])
+            fx["layout"] = layout
+            for k, e in model.edge_index_dict.items():
+                fx[f"edges.{k}"] = e.numpy().copy()
+            for k, v in model.state_dict().items():
+                fx["init." + k] = v.numpy().copy()
+            bs = batches_for(ds, 3, B, seed)
+            fx["batches"] = np.stack(bs)
+            with torch.no_grad():
+                for t, o in enumerate(model.forward()):
+                    fx[f"out.{t}"] = o.numpy().copy()
+            lx = model.loss(torch.from_numpy(bs[0]))
+            fx["loss_parts"] = np.array([float(v) for v in lx], dtype=np.float64)
+            model.zero_grad()
+            sum(lx).backward()
+            for k, p in model.named_parameters():
+                fx["grad." + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+            # TransE phase on (head, relation, pos tail, neg tail) rows drawn from the model's own edge lists
+            rng = np.random.RandomState(seed)
+            n_all = ds.num["user"] + ds.num["item"] + ds.num["tag"]
+            quads = []
+            for k, e in model.edge_index_dict.items():
+                e = e.numpy() if layout == "pairs" else e.numpy().T
+                pick = rng.randint(0, len(e), 12)
+                quads.append(np.stack([e[pick, 0], np.full(12, k), e[pick, 1], rng.randint(0, n_all, 12)], 1))
+            tb = np.concatenate(quads).astype(np.int64)
+            fx["transe_batch"] = tb
+            lt = model.transe_loss(torch.from_numpy(tb))
+            fx["transe_loss_parts"] = np.array([float(v) for v in lt], dtype=np.float64)
+            model.zero_grad()
+            sum(lt).backward()
+            for k, p in model.named_parameters():
+                if p.grad is not None:
+                    fx["transe_grad." + k] = p.grad.numpy().copy()
+            init = {k: v.clone() for k, v in model.state_dict().items()}
+            for n in (1, 3):
+                model.load_state_dict(init)
+                losses = run_steps(model, model.loss, bs, 0.01, n)
+                fx[f"step{n}.losses"] = np.array(losses, dtype=np.float64)
+                for k, v in model.state_dict().items():
+                    fx[f"step{n}." + k] = v.numpy().copy()
+            model.eval()
+            with torch.no_grad():
+                users = torch.arange(0, min(ds.num["user"], 16))
+                fx["predict.users"] = users.numpy()
+                fx["predict.rating"] = model.predict_rating(users).numpy().copy()
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+            print("wrote", name, {k: v for k, v in fx.items() if np.ndim(v) == 0})
+
+        kgat_case("kgat_toy", toy, "bi_inter", (64, 32, 16), 64, 64, 1e-3, 64, 34)                 # [E, 2] edge arrays
+        kgat_case("kgat_toy_wired", toy, "bi_inter", (64, 32), 64, 32, 1e-3, 64, 36, "wired")     # [2, E], as com.py wires it
+        kgat_case("kgat_toy_default", toy, "bi_agg", (64,), 64, 32, 1e-3, 64, 35, "wired")         # default agg_type: no propagation
         if only == "siblings":
             return
 
@@ -184,14 +266,6 @@ def main(only=None):
     np.savez_compressed(os.path.join(OUT, "adj_toy.npz"), **fx)
 
     # ------------------------------------------------------------------ helpers for model cases
-    def run_steps(model, loss_fn, batches, lr, n_steps):
-        """zero_grad / backward / Adam.step exactly as basic_train.epoch_training does,
-        via the reference's own epoch_training on a tiny producer object."""
-        prod = types.SimpleNamespace(reset=lambda: None,
-                                     mini_batch=lambda: iter([torch.from_numpy(b) for b in batches[:n_steps]]))
-        opt = torch.optim.Adam(model.parameters(), lr=lr)
-        return R["basic_train"].epoch_training(prod, loss_fn, opt)
-
     def model_case(name, ds, model_name, use_tag, layers, D, reg, B, seed):
         set_cfg(model_name, use_tag=use_tag, dim_layer_list=list(layers), dim_latent=D, reg=reg)
         torch.manual_seed(2020)                                          # init_seed (utility/utils.py:10-15)

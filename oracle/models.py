@@ -312,6 +312,67 @@ def disengcn_loss(tables, layers, rows, cols, factor_k, iterate_k, batch, reg, k
     return mul_loss(ue, pe, ne, kind), reg * l2reg_loss(ue, pe, ne)
 
 
+# --------------------------------------------------------------------------- KGAT
+def kgat_attention(all_embed, trans_e, relation, edges):
+    """Attention logits and the row softmax of `KGAT.forward` (model/kgat.py:63-104, split_adj_k == 1 branch):
+    per relation k:  pai = sum((e_tail W_k) * tanh(e_head W_k + r_k)); the edge lists are concatenated into ONE
+    sparse tensor and `torch.sparse.softmax(dim=1)` normalises each row (duplicate entries are summed by its
+    coalesce first).  `edges[k]` is a 2-D integer tensor read exactly as the reference reads it -- head =
+    `e[:, 0]`, tail = `e[:, 1]` (kgat.py:71-72) -- so an [E, 2] array (the layout of
+    `KGAT_load.get_relation_dict`, data/kgat_load.py:53-63) gives E edges, while the [2, E] arrays of
+    `TGCN_load.create_edge` (data/tgcn_load.py:55-71), which is what com.py:78-79 passes in, give two."""
+    pai, rows, cols = [], [], []
+    for k in sorted(edges.keys()):
+        row, col = edges[k][:, 0].long(), edges[k][:, 1].long()
+        tr = torch.matmul(all_embed[col], trans_e[k])
+        hr = torch.matmul(all_embed[row], trans_e[k]) + relation[k]
+        pai.append(torch.sum(tr * torch.tanh(hr), dim=1))
+        rows.append(row)
+        cols.append(col)
+    n = all_embed.shape[0]
+    adj = torch.sparse_coo_tensor(torch.stack([torch.cat(rows), torch.cat(cols)]), torch.cat(pai), (n, n))
+    return torch.sparse.softmax(adj, dim=1)
+
+
+def kgat_forward(prm, edges, n_user, n_layer, agg_type="bi_inter"):
+    """`KGAT.forward` + `bi_inter_embed` (kgat.py:63-126).  prm keys as the reference's state_dict
+    (`embed.user`, `embed.entity`, `embed.relation`, `mat.transE`, `mat.W1_k`, ...).  With any `agg_type` other
+    than "bi_inter" -- including the reference's own default "bi_agg" -- no propagation happens (kgat.py:100-101)."""
+    all_embed = torch.cat([prm["embed.user"], prm["embed.entity"]], dim=0)
+    if agg_type == "bi_inter":
+        adj = kgat_attention(all_embed, prm["mat.transE"], prm["embed.relation"], edges)
+        outs = [all_embed]
+        for k in range(n_layer):
+            nei = torch.sparse.mm(adj, all_embed)
+            s = F.leaky_relu(torch.matmul(nei + all_embed, prm[f"mat.W1_{k}"] + prm[f"mat.b1_{k}"]), 0.2)
+            b = F.leaky_relu(torch.matmul(nei * all_embed, prm[f"mat.W2_{k}"] + prm[f"mat.b2_{k}"]), 0.2)
+            all_embed = s + b
+            outs.append(F.normalize(all_embed, p=2, dim=1))
+        all_embed = torch.cat(outs, dim=1)
+    return all_embed[:n_user], all_embed[n_user:]
+
+
+def kgat_loss(prm, edges, n_user, n_layer, batch, reg, agg_type="bi_inter", kind="softplus"):
+    """`KGAT.loss` (kgat.py:143-153): items index the ENTITY table; L2 on the propagated rows."""
+    users, ents = kgat_forward(prm, edges, n_user, n_layer, agg_type)
+    ue, pe, ne = users[batch[:, 0]], ents[batch[:, 1]], ents[batch[:, 2]]
+    return mul_loss(ue, pe, ne, kind), reg * l2reg_loss(ue, pe, ne)
+
+
+def kgat_transe_loss(prm, batch, cor_reg):
+    """`KGAT.get_embed` + `transe_loss` (kgat.py:128-162): rows (head, relation, pos tail, neg tail)."""
+    all_embed = torch.cat([prm["embed.user"], prm["embed.entity"]], dim=0)
+    head, rela, pt, nt = batch[:, 0], batch[:, 1], batch[:, 2], batch[:, 3]
+    r_e = prm["embed.relation"][rela]
+    W = prm["mat.transE"][rela]
+    h_e = torch.matmul(all_embed[head].unsqueeze(1), W).squeeze()
+    p_e = torch.matmul(all_embed[pt].unsqueeze(1), W).squeeze()
+    n_e = torch.matmul(all_embed[nt].unsqueeze(1), W).squeeze()
+    pos = torch.norm(h_e + r_e - p_e, p=2, dim=1).pow(2)
+    neg = torch.norm(h_e + r_e - n_e, p=2, dim=1).pow(2)
+    return torch.mean(F.softplus(pos - neg)), cor_reg * l2reg_loss(h_e, r_e, p_e, n_e)
+
+
 def predict_rating(user_out, item_out, users):
     """`predict_rating` (lightgcn.py:84-89): sigmoid(U_b I^T)."""
     return torch.sigmoid(torch.matmul(user_out[users], item_out.t()))

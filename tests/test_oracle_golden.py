@@ -191,6 +191,41 @@ def test_disengcn_oracle(golden):
         np.testing.assert_allclose(b.grad.numpy(), fx[f"grad.layer.{k}.b"], rtol=1e-4, atol=1e-9)
 
 
+def kgat_edges(fx):
+    """The relation -> edge-array dict the reference model was given (saved verbatim in the fixture)."""
+    ks = sorted(int(k[6:]) for k in fx if k.startswith("edges."))
+    return {k: torch.from_numpy(fx[f"edges.{k}"].astype(np.int64)) for k in ks}
+
+
+def _kgat_params(fx, prefix="init."):
+    return {k[len(prefix):]: torch.from_numpy(fx[k].copy()) for k in fx if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("name", ["kgat_toy", "kgat_toy_wired", "kgat_toy_default"])
+def test_kgat_oracle(golden, name):
+    fx = golden(name)
+    edges, nu, L, agg = kgat_edges(fx), int(fx["n_user"]), len(fx["layers"]), str(fx["agg_type"])
+    prm = {k: v.requires_grad_() for k, v in _kgat_params(fx).items()}
+    users, ents = om.kgat_forward(prm, edges, nu, L, agg)
+    np.testing.assert_allclose(users.detach().numpy(), fx["out.0"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ents.detach().numpy(), fx["out.1"], rtol=1e-5, atol=1e-7)
+    batch = torch.from_numpy(fx["batches"][0])
+    loss, reg = om.kgat_loss(prm, edges, nu, L, batch, float(fx["reg"]), agg)
+    np.testing.assert_allclose([float(loss), float(reg)], fx["loss_parts"], rtol=1e-6)
+    (loss + reg).backward()
+    for k, p in prm.items():
+        want = fx["grad." + k]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(want)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-9 + 1e-6 * np.abs(want).max(), err_msg=k)
+    prm = {k: v.requires_grad_() for k, v in _kgat_params(fx).items()}
+    lt, rt = om.kgat_transe_loss(prm, torch.from_numpy(fx["transe_batch"]), float(fx["cor_reg"]))
+    np.testing.assert_allclose([float(lt), float(rt)], fx["transe_loss_parts"], rtol=1e-6)
+    (lt + rt).backward()
+    for k, p in prm.items():
+        if "transe_grad." + k in fx:
+            np.testing.assert_allclose(p.grad.numpy(), fx["transe_grad." + k], rtol=1e-4, atol=1e-9, err_msg=k)
+
+
 def test_predict_rating(golden):
     fx = golden("lightgcn_toy")
     A, L = _adj(fx), len(fx["layers"])
