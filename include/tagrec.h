@@ -141,7 +141,10 @@ int tagrec_bpr_bwd_f32(const float* U, const float* I, int64_t ld, int D,
  *   route_score        : logits[j, k] (+)= < H[row_j, slice k], T[col_j, slice k] >
  *   slice_scale        : Y[r, slice k] = scale[r, k] * X[r, slice k]
  *   slice_norm_fwd     : Y = X / max(||X slice||, 1e-12) per slice (then tanh if apply_tanh); inv (may be NULL) as above
- *   slice_norm_bwd     : gradient of slice_norm_fwd (without tanh) given X_raw, inv and dZ */
+ *   slice_norm_bwd     : gradient of slice_norm_fwd (without tanh) given X_raw, inv and dZ
+ *   row_softmax_fwd    : a[j] = softmax of logits over the stored entries of j's row (torch.sparse.softmax(adj, dim=1),
+ *                        model/kgat.py:96);  row_softmax_bwd : dlogits = a * (da - sum_row(a * da))
+ * D in {16,32,64,128,256} for the routed kernels. */
 int tagrec_route_softmax_f32(const float* logits, float* w, int64_t nnz, int K, void* stream);
 int tagrec_route_rowsum_rsqrt_f32(const tagrec_graph* g, const float* w, int K, float* d, void* stream);
 int tagrec_route_permute_f32(const float* w, const int32_t* perm, float* wt, int64_t nnz, int K, void* stream);
@@ -155,6 +158,8 @@ int tagrec_slice_norm_fwd_f32(const float* X, float* Y, float* inv, int64_t n_ro
                               void* stream);
 int tagrec_slice_norm_bwd_f32(const float* X_raw, const float* inv, const float* dZ, float* dX, int64_t n_rows, int D,
                               int K, void* stream);
+int tagrec_row_softmax_fwd_f32(const tagrec_graph* g, const float* logits, float* a, void* stream);
+int tagrec_row_softmax_bwd_f32(const tagrec_graph* g, const float* a, const float* da, float* dlogits, void* stream);
 
 /* ---- evaluation: sigmoid(U_b I^T) -> mask train positives -> top-K, fused (lightgcn.py:84-89, basic_test.py:36-50) --
  * U / I: propagated user / item tables, row-major [*, D].  users: int64 [n_users] ids to score.  train_ptr int64

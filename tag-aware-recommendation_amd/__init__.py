@@ -8,7 +8,7 @@ There is no CPU fallback: every op raises if the library or a GPU is missing.
 Reference name                      here
   model.help.split_mm / mul_loss ...  tagrec_amd.help
   model.LightGCN / NGCF / TGCN        tagrec_amd.LightGCN / NGCF / TGCN
-  model.DGCF / DisenGCN               tagrec_amd.DGCF / DisenGCN
+  model.DGCF / DisenGCN / KGAT        tagrec_amd.DGCF / DisenGCN / KGAT
   train_data.BPR_training_data        tagrec_amd.BPR_training_data
   training.Basic_train / Basic_test   tagrec_amd.Basic_train / Basic_test
   training.basic_train.epoch_training tagrec_amd.epoch_training
@@ -25,6 +25,7 @@ from .ngcf import NGCF  # noqa: F401
 from .tgcn import TGCN  # noqa: F401
 from .dgcf import DGCF  # noqa: F401
 from .disengcn import DisenGCN  # noqa: F401
+from .kgat import KGAT  # noqa: F401
 from .train import Adam, Basic_train, Early_stop, epoch_training  # noqa: F401
 from .train_data import (Abstract_training_data, BPR_training_data, DGCF_training_data,  # noqa: F401
-                         Fixed_training_data, TransTag_training_data)
+                         Fixed_training_data, KGAT_training_data, TransTag_training_data)

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "tagrec_slice_scale_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "tagrec_slice_norm_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     "tagrec_slice_norm_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
+    "tagrec_row_softmax_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "tagrec_row_softmax_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_eval_topk_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                              c_void_p, c_void_p],
     "tagrec_sample_negative_i64": [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, ctypes.c_uint64, c_void_p, c_void_p],

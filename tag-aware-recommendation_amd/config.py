@@ -27,6 +27,8 @@ _PER_MODEL = {
     # utility/config.py:14-30
     "dgcf": {"mul_loss_func": "softplus", "norm_type": "plain", "factor_k": 4, "iterate_k": 2, "cor_batch": 100},
     "disengcn": {"mul_loss_func": "softplus", "norm_type": "plain", "factor_k": 4, "iterate_k": 2, "cor_batch": 100},
+    # utility/config.py:54-61 -- note the default agg_type "bi_agg" switches KGAT's propagation off (kgat.py:100)
+    "kgat": {"dim_relation": 64, "transe_reg": 0.0001, "transe_batch": 1024, "agg_type": "bi_agg", "mul_loss_func": "softplus"},
 }
 
 

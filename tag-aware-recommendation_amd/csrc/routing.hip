@@ -333,6 +333,42 @@ __global__ void route_permute_kernel(const float* __restrict__ W, const int32_t*
   for (int k = 0; k < K; ++k) Wt[i * K + k] = W[src * K + k];
 }
 
+// ---- softmax over the stored entries of every CSR row (torch.sparse.softmax(adj, dim=1), kgat.py:96) and its backward ----
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 1; m < kWave; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void row_softmax_fwd_kernel(GraphView g, const float* __restrict__ logits,
+                                                                                  float* __restrict__ a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (r >= g.n_rows) return;
+  const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
+  float mx = -INFINITY;
+  for (int64_t j = start + lane; j < end; j += kWave) mx = fmaxf(mx, logits[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int64_t j = start + lane; j < end; j += kWave) sum += expf(logits[j] - mx);
+  sum = lanes_sum<kWave>(sum);
+  for (int64_t j = start + lane; j < end; j += kWave) a[j] = expf(logits[j] - mx) / sum;
+}
+
+// dlogit = a * (da - sum_row(a * da))
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void row_softmax_bwd_kernel(GraphView g, const float* __restrict__ a,
+                                                                                  const float* __restrict__ da,
+                                                                                  float* __restrict__ dlogits) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (r >= g.n_rows) return;
+  const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
+  float dot = 0.f;
+  for (int64_t j = start + lane; j < end; j += kWave) dot = fmaf(a[j], da[j], dot);
+  dot = lanes_sum<kWave>(dot);
+  for (int64_t j = start + lane; j < end; j += kWave) dlogits[j] = a[j] * (da[j] - dot);
+}
+
 // ---- per-slice row operations on [N, D] (thread per float4; a slice = SL consecutive lanes) -------------------
 enum SliceOp { SLICE_SCALE = 0, SLICE_NORM = 1, SLICE_NORM_TANH = 2, SLICE_NORM_BWD = 3 };
 
@@ -374,7 +410,7 @@ using namespace tagrec;
 namespace {
 
 bool route_shape_ok(int D, int K) {
-  if (!(D == 32 || D == 64 || D == 128 || D == 256)) return false;
+  if (!(D == 16 || D == 32 || D == 64 || D == 128 || D == 256)) return false;
   if (!(K == 1 || K == 2 || K == 4 || K == 8)) return false;
   return (D / 4) % K == 0;
 }
@@ -383,9 +419,10 @@ bool route_shape_ok(int D, int K) {
 template <typename F>
 int route_dispatch(int D, int K, const char* who, F&& f) {
   if (!route_shape_ok(D, K))
-    return fail(TAGREC_E_UNSUPPORTED, std::string(who) + ": needs D in {32,64,128,256}, K in {1,2,4,8}, D/K a multiple of 4 (got D=" +
+    return fail(TAGREC_E_UNSUPPORTED, std::string(who) + ": needs D in {16,32,64,128,256}, K in {1,2,4,8}, D/K a multiple of 4 (got D=" +
                                           std::to_string(D) + ", K=" + std::to_string(K) + ")");
 #define ROUTE_CASE(LPRV, KV) if (D == LPRV * 4 && K == KV) return f(std::integral_constant<int, LPRV>{}, std::integral_constant<int, KV>{});
+  ROUTE_CASE(4, 1) ROUTE_CASE(4, 2) ROUTE_CASE(4, 4)
   ROUTE_CASE(8, 1) ROUTE_CASE(8, 2) ROUTE_CASE(8, 4) ROUTE_CASE(8, 8)
   ROUTE_CASE(16, 1) ROUTE_CASE(16, 2) ROUTE_CASE(16, 4) ROUTE_CASE(16, 8)
   ROUTE_CASE(32, 1) ROUTE_CASE(32, 2) ROUTE_CASE(32, 4) ROUTE_CASE(32, 8)
@@ -550,4 +587,26 @@ extern "C" int tagrec_slice_norm_bwd_f32(const float* X_raw, const float* inv, c
                                          int K, void* stream) {
   TAGREC_REQUIRE(inv && dZ, "slice_norm_bwd: null inv or dZ");
   return launch_slice<SLICE_NORM_BWD>(X_raw, inv, dZ, dX, nullptr, n_rows, D, K, stream, "slice_norm_bwd");
+}
+
+extern "C" int tagrec_row_softmax_fwd_f32(const tagrec_graph* g, const float* logits, float* a, void* stream) {
+  TAGREC_REQUIRE(g, "row_softmax_fwd: null graph");
+  TAGREC_REQUIRE(g->nnz == 0 || (logits && a), "row_softmax_fwd: null pointer");
+  if (g->n_rows == 0 || g->nnz == 0) return TAGREC_OK;
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  row_softmax_fwd_kernel<<<blocks, kWavesPerBlock * kWave, 0, static_cast<hipStream_t>(stream)>>>(gv, logits, a);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_row_softmax_bwd_f32(const tagrec_graph* g, const float* a, const float* da, float* dlogits, void* stream) {
+  TAGREC_REQUIRE(g, "row_softmax_bwd: null graph");
+  TAGREC_REQUIRE(g->nnz == 0 || (a && da && dlogits), "row_softmax_bwd: null pointer");
+  if (g->n_rows == 0 || g->nnz == 0) return TAGREC_OK;
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  row_softmax_bwd_kernel<<<blocks, kWavesPerBlock * kWave, 0, static_cast<hipStream_t>(stream)>>>(gv, a, da, dlogits);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
 }

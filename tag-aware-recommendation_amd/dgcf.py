@@ -47,7 +47,7 @@ class _RoutedLayer(torch.autograd.Function):
         f, inv, d, w = ctx.saved_tensors
         rg = ctx.rg
         df = R.slice_norm_bwd(f, inv, g.contiguous())                         # through F.normalize (:87)
-        dx, _, _ = rg.spmm(rg.permute(w), R.slice_scale(df, d), post=d)       # (D A D)^T = D A^T D
+        dx, _, _ = rg.spmm(w, R.slice_scale(df, d), post=d, transposed=True)   # (D A D)^T = D A^T D
         return dx, None, None, None, None, None
 
 

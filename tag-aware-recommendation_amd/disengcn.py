@@ -40,7 +40,7 @@ class _Route(torch.autograd.Function):
         raw, inv, w = ctx.saved_tensors
         rg = ctx.rg
         draw = R.slice_norm_bwd(raw, inv, g.contiguous())
-        df, _, _ = rg.spmm(rg.permute(w), draw, self_add=draw)
+        df, _, _ = rg.spmm(w, draw, self_add=draw, transposed=True)
         return df, None, None, None
 
 

@@ -13,23 +13,41 @@ from .graph import Graph
 
 
 class RoutingGraph:
-    """Structure of a symmetric adjacency + the permutation that reorders per-entry data into the entry order of
-    the transposed matrix (for a symmetric structure that matrix has the same rowptr / col)."""
+    """Structure of an adjacency (values unused) + what the backward products need: the transposed structure and the
+    permutation that reorders per-entry data into its entry order.  For a symmetric structure (DGCF / DisenGCN: the
+    "plain" tag-aware adjacency) the transposed matrix has the same rowptr / col and only the permutation is kept."""
 
     def __init__(self, graph):
         if not isinstance(graph, Graph):
             raise _lib.TagrecError("RoutingGraph: needs a single Graph (row folds are not supported)")
         self.graph = graph
-        n = graph.shape[0]
+        n_rows, n_cols = graph.shape
         deg = graph.rowptr[1:] - graph.rowptr[:-1]
-        rows = torch.repeat_interleave(torch.arange(n, device=graph.device), deg)
+        rows = torch.repeat_interleave(torch.arange(n_rows, device=graph.device), deg)
         cols = graph.col.long()
-        perm = torch.argsort(cols * n + rows)
-        if graph.shape[0] != graph.shape[1] or not (torch.equal(rows[perm], cols) and torch.equal(cols[perm], rows)):
-            raise _lib.TagrecError("RoutingGraph: the adjacency structure must be symmetric")
+        perm = torch.argsort(cols * n_rows + rows, stable=True)
+        self.symmetric = n_rows == n_cols and torch.equal(rows[perm], cols) and torch.equal(cols[perm], rows)
+        if self.symmetric:
+            self.graph_t = graph
+        else:
+            rowptr_t = torch.zeros(n_cols + 1, dtype=torch.int64, device=graph.device)
+            torch.cumsum(torch.bincount(cols, minlength=n_cols), 0, out=rowptr_t[1:])
+            self.graph_t = Graph(rowptr_t, rows[perm].to(torch.int32).contiguous(), graph.val[perm].contiguous(), (n_cols, n_rows))
         self.rows, self.cols = rows, cols
         self.perm = perm.to(torch.int32).contiguous()
-        self.nnz, self.n, self.device = int(cols.numel()), n, graph.device
+        self.nnz, self.n, self.device = int(cols.numel()), n_rows, graph.device
+
+    @classmethod
+    def from_edges(cls, rows, cols, n, device):
+        """CSR over the given (row, col) entries, duplicates kept as separate entries.  Returns (RoutingGraph, order):
+        CSR entry j is input edge order[j]."""
+        rows = torch.as_tensor(rows, dtype=torch.int64, device=device)
+        cols = torch.as_tensor(cols, dtype=torch.int64, device=device)
+        order = torch.argsort(rows * n + cols, stable=True)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        torch.cumsum(torch.bincount(rows, minlength=n), 0, out=rowptr[1:])
+        g = Graph(rowptr, cols[order].to(torch.int32).contiguous(), torch.ones(rows.numel(), dtype=torch.float32, device=device), (n, n))
+        return cls(g), order
 
     # ---- kernels ------------------------------------------------------------------------------------------
     def softmax(self, logits):
@@ -50,14 +68,19 @@ class RoutingGraph:
                                                         _lib.stream_ptr()), "route_permute")
         return wt
 
-    def spmm(self, w, x, post=None, self_add=None, b=None, b_scale=0.0, raw=True, normed=False):
-        """(Y, Yn, inv): y = post * (A(w) x) + self_add + b_scale * b;  Yn / inv = per-slice L2 normalisation of y."""
+    def spmm(self, w, x, post=None, self_add=None, b=None, b_scale=0.0, raw=True, normed=False, transposed=False):
+        """(Y, Yn, inv): y = post * (A(w) x) + self_add + b_scale * b;  Yn / inv = per-slice L2 normalisation of y.
+        transposed=True: A(w)^T x (w in the ORIGINAL entry order; it is permuted here)."""
         _lib.require_gpu_tensor(x, torch.float32, "route_spmm x")
+        g = self.graph
+        if transposed:
+            g, w = self.graph_t, self.permute(w)
         K, D = w.shape[1], x.shape[1]
-        y = torch.empty_like(x) if raw else None
-        yn = torch.empty_like(x) if normed else None
-        inv = torch.empty(self.n, K, dtype=torch.float32, device=self.device) if normed else None
-        self.graph._call("route_spmm", _lib.load().tagrec_route_spmm_f32, self.graph.handle, _lib.ptr(w), K, _lib.ptr(x),
+        n_out = g.shape[0]
+        y = torch.empty(n_out, D, dtype=torch.float32, device=self.device) if raw else None
+        yn = torch.empty(n_out, D, dtype=torch.float32, device=self.device) if normed else None
+        inv = torch.empty(n_out, K, dtype=torch.float32, device=self.device) if normed else None
+        self.graph._call("route_spmm", _lib.load().tagrec_route_spmm_f32, g.handle, _lib.ptr(w), K, _lib.ptr(x),
                          _lib.ptr(post), _lib.ptr(self_add), _lib.ptr(b), float(b_scale), _lib.ptr(y), _lib.ptr(yn),
                          _lib.ptr(inv), D, _lib.stream_ptr())
         return y, yn, inv
@@ -65,6 +88,88 @@ class RoutingGraph:
     def score(self, h, t, logits, accumulate):
         self.graph._call("route_score", _lib.load().tagrec_route_score_f32, self.graph.handle, _lib.ptr(h), _lib.ptr(t),
                          _lib.ptr(logits), logits.shape[1], int(bool(accumulate)), h.shape[1], _lib.stream_ptr())
+
+
+    def row_softmax(self, logits):
+        a = torch.empty_like(logits)
+        _lib.check(_lib.load().tagrec_row_softmax_fwd_f32(self.graph.handle, _lib.ptr(logits), _lib.ptr(a), _lib.stream_ptr()),
+                   "row_softmax_fwd")
+        return a
+
+    def row_softmax_bwd(self, a, da):
+        dl = torch.empty_like(a)
+        _lib.check(_lib.load().tagrec_row_softmax_bwd_f32(self.graph.handle, _lib.ptr(a), _lib.ptr(da), _lib.ptr(dl),
+                                                          _lib.stream_ptr()), "row_softmax_bwd")
+        return dl
+
+
+# ---- differentiable edge-value operators (KGAT: attention values carry gradient, model/kgat.py:88-104) --------------
+class _EdgeScore(torch.autograd.Function):
+    """s[j] = < H[row_j], T[col_j] > for every stored entry j."""
+
+    @staticmethod
+    def forward(ctx, H, T, rg):
+        H, T = H.contiguous(), T.contiguous()
+        s = torch.empty(rg.nnz, 1, dtype=torch.float32, device=H.device)
+        rg.score(H, T, s, accumulate=False)
+        ctx.rg = rg
+        ctx.save_for_backward(H, T)
+        return s.view(-1)
+
+    @staticmethod
+    def backward(ctx, ds):
+        H, T = ctx.saved_tensors
+        ds = ds.contiguous().view(-1, 1)
+        dH, _, _ = ctx.rg.spmm(ds, T)                       # dH[r] = sum_j ds_j T[col_j]
+        dT, _, _ = ctx.rg.spmm(ds, H, transposed=True)      # dT[c] = sum_j ds_j H[row_j]
+        return dH, dT, None
+
+
+class _RowSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, rg):
+        a = rg.row_softmax(logits.contiguous())
+        ctx.rg = rg
+        ctx.save_for_backward(a)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        (a,) = ctx.saved_tensors
+        return ctx.rg.row_softmax_bwd(a, da.contiguous()), None
+
+
+class _ValuedSpMM(torch.autograd.Function):
+    """Y = A(a) X with gradient to the entry values a AND to X (torch.sparse.mm on a sparse tensor with grad)."""
+
+    @staticmethod
+    def forward(ctx, a, X, rg):
+        X = X.contiguous()
+        y, _, _ = rg.spmm(a.contiguous().view(-1, 1), X)
+        ctx.rg = rg
+        ctx.save_for_backward(a, X)
+        return y
+
+    @staticmethod
+    def backward(ctx, dY):
+        a, X = ctx.saved_tensors
+        dY = dY.contiguous()
+        dX, _, _ = ctx.rg.spmm(a.view(-1, 1), dY, transposed=True)
+        da = torch.empty(ctx.rg.nnz, 1, dtype=torch.float32, device=dY.device)
+        ctx.rg.score(dY, X, da, accumulate=False)          # da_j = < dY[row_j], X[col_j] >
+        return da.view(-1), dX, None
+
+
+def edge_score(H, T, rg):
+    return _EdgeScore.apply(H, T, rg)
+
+
+def row_softmax(logits, rg):
+    return _RowSoftmax.apply(logits, rg)
+
+
+def valued_spmm(a, X, rg):
+    return _ValuedSpMM.apply(a, X, rg)
 
 
 def slice_scale(x, scale):

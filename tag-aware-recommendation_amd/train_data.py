@@ -143,6 +143,42 @@ class DGCF_training_data(Abstract_training_data):
             yield self.mini_sample()
 
 
+class KGAT_training_data(Abstract_training_data):
+    """TransE-phase producer of KGAT (train_data/transe_training_data.py:12-41): all (head, relation, tail) triplets of
+    `data.create_edge()` in relation order; batch i is the window `all_triplet[i : i + transe_batch]` -- consecutive
+    windows overlap in all but one row, as the reference's loop is written (:37-38) -- with one uniform negative
+    tail per row, rejected while (head, relation, tail) is a known triplet.  `reset()` does nothing."""
+
+    def __init__(self, data, args=None, config=None, seed=None):
+        super().__init__(args, config)
+        cfg = config if config is not None else _GLOBAL_CFG
+        self.batch_size = cfg["transe_batch"]
+        self.num = data.num["user"] + data.num["item"] + data.num["tag"]
+        parts = []
+        for k, e in data.create_edge().items():
+            e = torch.as_tensor(np.asarray(e), dtype=torch.int64)      # [2, E] (TGCN_load.create_edge); rows: head, tail
+            parts.append(torch.stack([e[0], torch.full_like(e[0], int(k)), e[1]], dim=1))
+        self.all_triplet = torch.cat(parts).to(self.device)
+        n_rel = int(self.all_triplet[:, 1].max()) + 1 if self.all_triplet.numel() else 1
+        self._n_rel = n_rel
+        self._pos = _Positives(self.all_triplet[:, 0] * n_rel + self.all_triplet[:, 1], self.all_triplet[:, 2], self.num * n_rel,
+                               self.num)
+        self.tot_inter = self.all_triplet.shape[0] // self.batch_size
+        self._seed = int(cfg["seed"] if seed is None else seed) + 2
+        self._draws = 0
+
+    def reset(self):
+        pass
+
+    def mini_batch(self):
+        for i in range(self.tot_inter):
+            batch = self.all_triplet[i:i + self.batch_size]
+            left = (batch[:, 0] * self._n_rel + batch[:, 1]).contiguous()
+            neg = self._pos.sample(left, (self._seed << 20) + self._draws)
+            self._draws += 1
+            yield torch.cat([batch, neg[:, None]], dim=1)
+
+
 class Fixed_training_data(Abstract_training_data):
     """Replays given per-epoch triplet arrays (parity runs against the CPU oracle)."""
 

@@ -127,10 +127,46 @@ def test_routing_rejects_bad_arguments():
         _lib = T._lib
         _lib.check(_lib.load().tagrec_route_spmm_f32(g.handle, _lib.ptr(w), 4, _lib.ptr(x), None, None, None, 0.0, _lib.ptr(x),
                                                      None, None, 64, _lib.stream_ptr()), "route_spmm")
-    # a non-symmetric structure is refused
-    csr = oadj.coo_to_csr(np.array([0, 1]), np.array([1, 2]), np.ones(2, np.float32), (3, 3))
-    with pytest.raises(T.TagrecError, match="symmetric"):
-        R.RoutingGraph(T.Graph.from_host(csr.rowptr, csr.col, csr.val, csr.shape, DEV))
+
+
+def test_edge_value_operators_on_a_non_symmetric_graph():
+    """edge_score / row_softmax / valued_spmm (the differentiable pieces KGAT is built from) against torch autograd on a
+    directed graph with duplicate entries and a long row; exercises the transposed structure + permutation."""
+    n, D = 1500, 32
+    rng = np.random.RandomState(2)
+    rows = np.concatenate([rng.randint(0, n, 9000), np.zeros(1200, np.int64), [3, 3, 3]])
+    cols = np.concatenate([rng.randint(0, n, 9000), rng.choice(n, 1200, replace=False), [7, 7, 9]])       # (3,7) twice
+    rg, order = R.RoutingGraph.from_edges(rows, cols, n, DEV)
+    assert not rg.symmetric and rg.nnz == len(rows)
+    r, c = rg.rows, rg.cols
+    assert torch.equal(r, torch.from_numpy(rows).to(DEV)[order]) and torch.equal(c, torch.from_numpy(cols).to(DEV)[order])
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    Hh = torch.randn(n, D, generator=gen).to(DEV).requires_grad_()
+    Tt = torch.randn(n, D, generator=gen).to(DEV).requires_grad_()
+    X = torch.randn(n, D, generator=gen).to(DEV).requires_grad_()
+    gy = torch.randn(n, D, generator=gen).to(DEV)
+
+    def pipeline(score, softmax, spmm):
+        a = softmax(0.3 * score(Hh, Tt))
+        return a, spmm(a, X)
+
+    def ref_softmax(s):
+        mx = torch.full((n,), -1e30, device=DEV).scatter_reduce(0, r, s.detach(), "amax")
+        e = torch.exp(s - mx[r])
+        return e / torch.zeros(n, device=DEV).index_add(0, r, e)[r]
+
+    a0, y0 = pipeline(lambda h, t: (h[r] * t[c]).sum(1), ref_softmax,
+                      lambda a, x: torch.zeros(n, D, device=DEV).index_add(0, r, a[:, None] * x[c]))
+    y0.backward(gy)
+    want = [t.grad.clone() for t in (Hh, Tt, X)]
+    for t in (Hh, Tt, X):
+        t.grad = None
+    a1, y1 = pipeline(lambda h, t: R.edge_score(h, t, rg), lambda s: R.row_softmax(s, rg), lambda a, x: R.valued_spmm(a, x, rg))
+    np.testing.assert_allclose(a1.detach().cpu().numpy(), a0.detach().cpu().numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(y1.detach().cpu().numpy(), y0.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    y1.backward(gy)
+    for t, w in zip((Hh, Tt, X), want):
+        np.testing.assert_allclose(t.grad.cpu().numpy(), w.cpu().numpy(), rtol=1e-3, atol=1e-4 * float(w.abs().max()))
 
 
 # ------------------------------------------------------------------ models against the reference's fixtures
@@ -276,3 +312,90 @@ def test_dgcf_training_data_producer():
     model = T.DGCF(ds, config=T.get_config("dgcf", device=DEV, train_batch=128, use_tag=True, dim_layer_list=[64]))
     losses = T.epoch_training(prod, model.loss, T.Adam(model.parameters(), lr=0.01), verbose=False)
     assert len(losses) == len(batches) and np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+# ------------------------------------------------------------------ KGAT
+class _KgatData:
+    def __init__(self, fx):
+        self.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
+        self._edges = {int(k[6:]): fx[k] for k in fx if k.startswith("edges.")}
+
+    def create_edge(self):
+        return {k: self._edges[k] for k in sorted(self._edges)}
+
+
+def _kgat(fx):
+    cfg = T.get_config("kgat", dim_layer_list=[int(x) for x in fx["layers"]], dim_latent=int(fx["D"]),
+                       dim_relation=int(fx["dim_relation"]), reg=float(fx["reg"]), agg_type=str(fx["agg_type"]),
+                       cor_reg=float(fx["cor_reg"]), device=DEV)
+    m = T.KGAT(_KgatData(fx), config=cfg)
+    assert list(m.state_dict().keys()) == [k[5:] for k in fx if k.startswith("init.")]
+    m.load_state_dict({k[5:]: torch.from_numpy(fx[k]) for k in fx if k.startswith("init.")})
+    return m
+
+
+@pytest.mark.parametrize("name", ["kgat_toy", "kgat_toy_wired", "kgat_toy_default"])
+def test_kgat_golden(golden, name):
+    fx = golden(name)
+    m = _kgat(fx)
+    m.train()
+    with torch.no_grad():
+        users, ents = m.forward()
+    np.testing.assert_allclose(users.cpu().numpy(), fx["out.0"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ents.cpu().numpy(), fx["out.1"], rtol=1e-4, atol=1e-6)
+    lossx = m.loss(torch.from_numpy(fx["batches"][0]).to(DEV))
+    np.testing.assert_allclose([float(v) for v in lossx], fx["loss_parts"], rtol=1e-5, atol=1e-8)
+    sum(lossx).backward()
+    for k, p in m.named_parameters():
+        want = fx["grad." + k]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(want)
+        if np.abs(want).max() == 0:
+            assert np.abs(got).max() <= 1e-12, k
+        else:
+            _grad_check(got, want)
+    # TransE phase
+    m.zero_grad()
+    lt = m.transe_loss(torch.from_numpy(fx["transe_batch"]).to(DEV))
+    np.testing.assert_allclose([float(v) for v in lt], fx["transe_loss_parts"], rtol=1e-5, atol=1e-8)
+    sum(lt).backward()
+    for k, p in m.named_parameters():
+        if "transe_grad." + k in fx:
+            _grad_check(p.grad.cpu().numpy(), fx["transe_grad." + k])
+    # step surface
+    for n_steps in (1, 3):
+        m = _kgat(fx)
+        m.train()
+        opt = T.Adam(m.parameters(), lr=float(fx["lr"]))
+        prod = T.Fixed_training_data([np.concatenate(fx["batches"][:n_steps])], fx["batches"].shape[1], DEV)
+        prod.mini_batch = lambda: iter([torch.from_numpy(b).to(DEV) for b in fx["batches"][:n_steps]])
+        losses = T.epoch_training(prod, m.loss, opt, verbose=False)
+        np.testing.assert_allclose(losses, fx[f"step{n_steps}.losses"], rtol=5e-5)
+        sd = m.state_dict()
+        for key in sd:
+            got, want = sd[key].cpu().numpy(), fx[f"step{n_steps}.{key}"]
+            assert np.mean(np.abs(got - want) <= 2e-5) >= 0.99, key
+            assert np.abs(got - want).max() <= 1e-3, key
+    m.eval()
+    m.load_state_dict({k[6:]: torch.from_numpy(fx[k]) for k in fx if k.startswith("step3.")})
+    got = m.predict_rating(torch.from_numpy(fx["predict.users"]).to(DEV))
+    assert got.shape == (len(fx["predict.users"]), int(fx["n_item"]) + int(fx["n_tag"]))
+    np.testing.assert_allclose(got.cpu().numpy(), fx["predict.rating"], rtol=1e-4, atol=1e-5)
+
+
+def test_kgat_training_data_producer(golden):
+    """`KGAT_training_data` (transe_training_data.py:12-41): windows shifted by ONE row, negatives never a known tail."""
+    fx = golden("kgat_toy_wired")
+    data = _KgatData(fx)
+    cfg = T.get_config("kgat", device=DEV, transe_batch=32)
+    prod = T.KGAT_training_data(data, config=cfg, seed=1)
+    n_tri = sum(v.shape[1] for v in data.create_edge().values())
+    assert prod.all_triplet.shape == (n_tri, 3) and prod.tot_inter == n_tri // 32
+    batches = list(prod.mini_batch())
+    assert len(batches) == prod.tot_inter
+    b0, b1 = batches[0].cpu().numpy(), batches[1].cpu().numpy()
+    assert b0.shape == (32, 4) and np.array_equal(b0[1:, :3], b1[:-1, :3])          # the stride-1 windows
+    known = set(map(tuple, prod.all_triplet.cpu().numpy().tolist()))
+    assert all((h, r, n) not in known for h, r, _, n in np.concatenate([b.cpu().numpy() for b in batches[:20]]).tolist())
+    # relation ids follow create_edge's keys; heads / tails its rows
+    e0 = data.create_edge()[0]
+    assert np.array_equal(prod.all_triplet[:e0.shape[1]].cpu().numpy(), np.stack([e0[0], np.zeros_like(e0[0]), e0[1]], 1))
