@@ -87,8 +87,11 @@ def test_config_defaults_match_reference():
     assert (n["mul_loss_func"], n["norm_type"], n["agg_type"]) == ("logsigmoid", "ngcf", "bi_agg")
     t = T.get_config("tgcn")
     assert (t["neighbor_k"], t["dim_atten"], t["num_bit_conv"], t["num_vec_conv"], t["margin"]) == (25, 32, 32, 8, 1)
+    d, k = T.get_config("dgcf"), T.get_config("kgat")
+    assert (d["factor_k"], d["iterate_k"], d["norm_type"], d["mul_loss_func"]) == (4, 2, "plain", "softplus")
+    assert (k["dim_relation"], k["transe_batch"], k["agg_type"]) == (64, 1024, "bi_agg")
     with pytest.raises(KeyError):
-        T.get_config("kgat")
+        T.get_config("disenhan")
 
 
 def test_text_loader_matches_reference_loader(golden, tmp_path):
