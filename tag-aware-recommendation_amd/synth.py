@@ -25,6 +25,21 @@ class Dataset:
         self.uit_data = None
         self.rel = None           # device CSR relations of the tripartite generator
 
+    def create_edge(self):
+        """`TGCN_load.create_edge` (data/tgcn_load.py:55-71): dict relation -> [2, E] arrays (head row, tail row) for
+        ui, iu, ut, tu, it, ti with node ids offset into [users | items | tags].  The reference's COO matrices hold
+        one entry per (u, i, t) assignment; a block stored here with summed counts is expanded back."""
+        def entries(c, row_off, col_off):
+            cnt = np.rint(np.asarray(c.data)).astype(np.int64)
+            return (np.repeat(np.asarray(c.row).astype(np.int64), cnt) + row_off,
+                    np.repeat(np.asarray(c.col).astype(np.int64), cnt) + col_off)
+        nu, ni = self.num["user"], self.num["item"]
+        out = {}
+        for k, (c, ro, co) in enumerate(((self.ui_adj, 0, nu), (self.ut_adj, 0, nu + ni), (self.it_adj, nu, nu + ni))):
+            r, cc = entries(c, ro, co)
+            out[2 * k], out[2 * k + 1] = np.stack([r, cc]), np.stack([cc, r])
+        return out
+
 
 def _zipf_weights(n, alpha):
     w = np.arange(1, n + 1, dtype=np.float64) ** (-alpha)

@@ -122,6 +122,17 @@ def test_text_loader_matches_reference_loader(golden, tmp_path):
     assert ld2.num == ld.num and np.array_equal(ld2.uit_data, ld.uit_data)
 
 
+def test_create_edge_matches_reference(golden):
+    """`Dataset.create_edge` against what the reference's `TGCN_load.create_edge` produced for the same dataset
+    (fixture kgat_toy_wired holds those arrays verbatim)."""
+    fx = golden("kgat_toy_wired")
+    toy = T.synth.make_cf_dataset(40, 30, 300, seed=1, n_tag=12, n_assign=200)
+    edges = toy.create_edge()
+    assert sorted(edges) == list(range(6))
+    for k in range(6):
+        assert np.array_equal(edges[k], fx[f"edges.{k}"])
+
+
 def test_early_stop_protocol(tmp_path):
     import types
     cfg = T.get_config("lightgcn", patient_epoch=1)
