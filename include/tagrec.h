@@ -194,6 +194,10 @@ int tagrec_transtag_bwd_f32(const float* Eu, const float* Ei, const float* Et, i
  *   m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
 int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
                     float lr, float b1, float b2, float eps, int64_t step, void* stream);
+/* The same update with the step counter (int64[1]) and the two step-dependent factors (float[2], scratch) in DEVICE
+ * memory: the call advances *step_dev itself, so a HIP graph that captured it replays as successive steps. */
+int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* v, int64_t n,
+                          float lr, float b1, float b2, float eps, int64_t* step_dev, float* coef_dev, void* stream);
 
 /* ---- NGCF layer, dense half (ngcf.py:77-86), exact-fp32 MFMA ------------------------------------------
  * Given N = A @ X (tagrec_spmm_f32) and W1p = W1 + b1, W2p = W2 + b2 (row-major [Din, Dout]; the

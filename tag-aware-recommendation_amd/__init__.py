@@ -26,6 +26,6 @@ from .tgcn import TGCN  # noqa: F401
 from .dgcf import DGCF  # noqa: F401
 from .disengcn import DisenGCN  # noqa: F401
 from .kgat import KGAT  # noqa: F401
-from .train import Adam, Basic_train, Early_stop, epoch_training  # noqa: F401
+from .train import Adam, Basic_train, Early_stop, GraphedStep, epoch_training  # noqa: F401
 from .train_data import (Abstract_training_data, BPR_training_data, DGCF_training_data,  # noqa: F401
                          Fixed_training_data, KGAT_training_data, TransTag_training_data)

@@ -84,6 +84,8 @@ _SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int64,
                         c_void_p],
+    "tagrec_adam_graph_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                              c_void_p, c_void_p, c_void_p],
 }
 
 _lib = None

@@ -16,6 +16,7 @@ _BASE = {
     "epochs": 1000, "dim_latent": 64, "dim_layer_list": [64, 32, 16],
     "message_drop_list": [0.0, 0.0, 0.0], "node_drop": 0.0,
     "seed": 2020, "cpu_core": 4, "split_adj_k": 1,
+    "hip_graph": False,       # Basic_train: replay each phase's step as one captured HIP graph (train.GraphedStep)
 }
 
 # utility/config.py:1-12, 41-52

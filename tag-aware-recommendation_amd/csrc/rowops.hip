@@ -343,7 +343,8 @@ __global__ __launch_bounds__(kThreads) void transtag_bwd_kernel(const float* __r
 __global__ __launch_bounds__(kThreads) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
                                                         float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
                                                         float w1, float b2, float w2, float step_size,
-                                                        float bc2_sqrt, float eps) {
+                                                        float bc2_sqrt, float eps, const float* __restrict__ coef) {
+  if (coef) { step_size = coef[0]; bc2_sqrt = coef[1]; }      // step-dependent factors kept on the device (graph capture)
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
     const float4 gi = g[i];
@@ -361,7 +362,9 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float4* __restrict__ p, 
 __global__ __launch_bounds__(kThreads) void adam_tail_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                              float* __restrict__ m, float* __restrict__ v,
                                                              int64_t start, int64_t n, float w1, float b2, float w2,
-                                                             float step_size, float bc2_sqrt, float eps) {
+                                                             float step_size, float bc2_sqrt, float eps,
+                                                             const float* __restrict__ coef) {
+  if (coef) { step_size = coef[0]; bc2_sqrt = coef[1]; }
   const int64_t i = start + static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i];
@@ -370,6 +373,17 @@ __global__ __launch_bounds__(kThreads) void adam_tail_kernel(float* __restrict__
   m[i] = mi;
   v[i] = vi;
   p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+}
+
+// step counter and the two step-dependent factors of Adam, advanced ON the device so a captured graph replays correctly
+__global__ void adam_advance_kernel(int64_t* __restrict__ step, float* __restrict__ coef, double lr, double b1, double b2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int64_t t = *step + 1;
+  *step = t;
+  const double bc1 = 1.0 - pow(b1, static_cast<double>(t));
+  const double bc2 = 1.0 - pow(b2, static_cast<double>(t));
+  coef[0] = static_cast<float>(lr / bc1);
+  coef[1] = static_cast<float>(sqrt(bc2));
 }
 
 }  // namespace tagrec
@@ -514,17 +528,9 @@ extern "C" int tagrec_transtag_bwd_f32(const float* Eu, const float* Ei, const f
   return TAGREC_OK;
 }
 
-extern "C" int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
-                               float eps, int64_t step, void* stream) {
-  TAGREC_REQUIRE(p && g && m && v, "adam: null pointer");
-  TAGREC_REQUIRE(n >= 0 && step >= 1, "adam: bad n or step");
-  if (n == 0) return TAGREC_OK;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  // same host arithmetic as torch's _single_tensor_adam (python floats = doubles)
-  const double bc1 = 1.0 - pow(static_cast<double>(b1), static_cast<double>(step));
-  const double bc2 = 1.0 - pow(static_cast<double>(b2), static_cast<double>(step));
-  const float step_size = static_cast<float>(static_cast<double>(lr) / bc1);
-  const float bc2_sqrt = static_cast<float>(sqrt(bc2));
+namespace {
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float b1, float b2, float eps, float step_size,
+                float bc2_sqrt, const float* coef, hipStream_t s) {
   const float w1 = static_cast<float>(1.0 - static_cast<double>(b1));
   const float w2 = static_cast<float>(1.0 - static_cast<double>(b2));
   const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
@@ -534,15 +540,39 @@ extern "C" int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int
     if (blocks > 256 * 16) blocks = 256 * 16;
     adam_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, s>>>(
         reinterpret_cast<float4*>(p), reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m),
-        reinterpret_cast<float4*>(v), n4, w1, b2, w2, step_size, bc2_sqrt, eps);
+        reinterpret_cast<float4*>(v), n4, w1, b2, w2, step_size, bc2_sqrt, eps, coef);
     TAGREC_LAUNCH_CHECK();
   }
   const int64_t done = n4 * 4;
   if (done < n) {
     const int64_t blocks = (n - done + kThreads - 1) / kThreads;
     adam_tail_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, s>>>(p, g, m, v, done, n, w1, b2, w2, step_size,
-                                                                        bc2_sqrt, eps);
+                                                                        bc2_sqrt, eps, coef);
     TAGREC_LAUNCH_CHECK();
   }
   return TAGREC_OK;
+}
+}  // namespace
+
+extern "C" int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                               float eps, int64_t step, void* stream) {
+  TAGREC_REQUIRE(p && g && m && v, "adam: null pointer");
+  TAGREC_REQUIRE(n >= 0 && step >= 1, "adam: bad n or step");
+  if (n == 0) return TAGREC_OK;
+  // same host arithmetic as torch's _single_tensor_adam (python floats = doubles)
+  const double bc1 = 1.0 - pow(static_cast<double>(b1), static_cast<double>(step));
+  const double bc2 = 1.0 - pow(static_cast<double>(b2), static_cast<double>(step));
+  return launch_adam(p, g, m, v, n, b1, b2, eps, static_cast<float>(static_cast<double>(lr) / bc1),
+                     static_cast<float>(sqrt(bc2)), nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                                     float eps, int64_t* step_dev, float* coef_dev, void* stream) {
+  TAGREC_REQUIRE(p && g && m && v && step_dev && coef_dev, "adam_graph: null pointer");
+  TAGREC_REQUIRE(n >= 0, "adam_graph: bad n");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  adam_advance_kernel<<<1, 1, 0, s>>>(step_dev, coef_dev, static_cast<double>(lr), static_cast<double>(b1), static_cast<double>(b2));
+  TAGREC_LAUNCH_CHECK();
+  if (n == 0) return TAGREC_OK;
+  return launch_adam(p, g, m, v, n, b1, b2, eps, 0.f, 1.f, coef_dev, s);
 }

@@ -2,6 +2,7 @@
 fused Adam that replaces `torch.optim.Adam` (com.py:14,25,69).
 
     epoch_training(training_data, loss_func, opt) -> list[float]      basic_train.py:10-30
+    GraphedStep / epoch_training(..., graphs={})                       the same step replayed as one HIP graph
     Basic_train(train_data, loss_func, opt, test, args).run(model)    basic_train.py:50-85
     Early_stop                                                         training/early_stop.py:8-41
     Adam(params, lr)   zero_grad()/step()                              torch.optim.Adam defaults
@@ -21,13 +22,16 @@ class Adam:
     HIP pass per parameter tensor.  Same zero_grad()/step() protocol, so it drops into
     `epoch_training` where the reference passes a torch optimizer."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        """capturable=True keeps every parameter's step counter in device memory and advances it inside the
+        update (tagrec_adam_graph_f32), so `step()` can be captured in a HIP graph and replayed (`GraphedStep`)."""
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("Adam: empty parameter list")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.state = {}
         self.step_count = 0
+        self.capturable = bool(capturable)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -49,31 +53,114 @@ class Adam:
             st = self.state.get(id(p))
             if st is None:
                 st = self.state[id(p)] = {"m": torch.zeros_like(p.data), "v": torch.zeros_like(p.data), "t": 0}
+                if self.capturable:
+                    st["t_dev"] = torch.zeros(1, dtype=torch.int64, device=p.device)
+                    st["coef"] = torch.zeros(2, dtype=torch.float32, device=p.device)
             st["t"] += 1
-            _lib.check(lib.tagrec_adam_f32(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
-                                           p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, st["t"],
-                                           _lib.stream_ptr()), "adam")
+            if self.capturable:
+                _lib.check(lib.tagrec_adam_graph_f32(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
+                                                     p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                     _lib.ptr(st["t_dev"]), _lib.ptr(st["coef"]), _lib.stream_ptr()),
+                           "adam_graph")
+            else:
+                _lib.check(lib.tagrec_adam_f32(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
+                                               p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, st["t"],
+                                               _lib.stream_ptr()), "adam")
+
+    def prepare_state(self):
+        """Allocate every parameter's state now (graph capture must not meet a first-use allocation whose zero fill
+        would be replayed)."""
+        for p in self.params:
+            if id(p) not in self.state:
+                st = self.state[id(p)] = {"m": torch.zeros_like(p.data), "v": torch.zeros_like(p.data), "t": 0}
+                if self.capturable:
+                    st["t_dev"] = torch.zeros(1, dtype=torch.int64, device=p.device)
+                    st["coef"] = torch.zeros(2, dtype=torch.float32, device=p.device)
 
 
-def epoch_training(training_data, loss_func, opt, verbose=True):
+def _step(loss_func, opt, data):
+    lossx = loss_func(data)
+    parts = torch.stack([x.detach() for x in lossx])
+    loss = sum(lossx)
+    if isinstance(opt, list):
+        [op.zero_grad() for op in opt]
+        loss.backward()
+        [op.step() for op in opt]
+    else:
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return parts
+
+
+class GraphedStep:
+    """One training step -- loss parts, backward, optimizer -- captured once as a HIP graph and replayed per batch.
+    At the reference's dataset sizes (HetRec / ml-100k: ~1e5 edges) a step is a few dozen to a few hundred small
+    launches and the GPU idles between them; replaying the captured graph removes the per-launch host cost.
+    The optimizer must advance its step counter on the device (`Adam(capturable=True)`), the batch shape is fixed,
+    and the step must not synchronise with the host (the fused model paths do not)."""
+
+    def __init__(self, loss_func, opt, batch):
+        opts = opt if isinstance(opt, list) else [opt]
+        for op in opts:
+            if not getattr(op, "capturable", False):
+                raise _lib.TagrecError("GraphedStep: the optimizer must be Adam(capturable=True)")
+            op.prepare_state()
+        self.static_batch = batch.clone()
+        self.graph = torch.cuda.CUDAGraph()
+        self._opts = opts
+        before = [op.step_count for op in opts]
+        [op.zero_grad() for op in opts]
+        with torch.cuda.graph(self.graph):
+            self.static_parts = _step(loss_func, opt, self.static_batch)
+        for op, b in zip(opts, before):          # capturing executed nothing: the host-side counters follow the replays
+            op.step_count = b
+
+    def __call__(self, batch):
+        self.static_batch.copy_(batch)
+        self.graph.replay()
+        for op in self._opts:
+            op.step_count += 1
+        return self.static_parts.clone()
+
+
+def _graph_key(loss_func, data):
+    owner = getattr(loss_func, "__self__", None)
+    return (id(owner), getattr(loss_func, "__name__", id(loss_func)), tuple(data.shape), data.dtype)
+
+
+def epoch_training(training_data, loss_func, opt, verbose=True, graphs=None):
     """One pass over `training_data.mini_batch()` (basic_train.py:10-30): per batch the loss parts,
     their sum, zero_grad / backward / step.  Returns the per-batch totals as floats.
     The reference synchronises twice per step to read the losses (:16,27); here the parts stay on
-    the device and are read back once at the end of the epoch -- same numbers, one sync."""
+    the device and are read back once at the end of the epoch -- same numbers, one sync.
+
+    graphs: a dict kept by the caller across epochs.  When given, the first two batches of every (loss function,
+    batch shape) run as usual -- they also grow every lazily sized buffer -- the third is captured as a HIP graph
+    (`GraphedStep`) and from then on batches of that shape are graph replays; other shapes (the merged tail
+    batch) and batches that are not plain tensors run as usual.  If a step cannot be captured it keeps running
+    eagerly and the reason is recorded under graphs["errors"]."""
     parts_dev = []
     training_data.reset()
     for data in training_data.mini_batch():
-        lossx = loss_func(data)
-        parts_dev.append(torch.stack([x.detach() for x in lossx]))
-        loss = sum(lossx)
-        if isinstance(opt, list):
-            [op.zero_grad() for op in opt]
-            loss.backward()
-            [op.step() for op in opt]
-        else:
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
+        if graphs is not None and isinstance(data, torch.Tensor) and data.is_cuda:
+            key = _graph_key(loss_func, data)
+            entry = graphs.get(key, 0)
+            if isinstance(entry, GraphedStep):
+                parts_dev.append(entry(data))
+                continue
+            if entry == 2:
+                try:
+                    graphs[key] = GraphedStep(loss_func, opt, data)
+                    parts_dev.append(graphs[key](data))
+                    continue
+                except Exception as exc:                 # not capturable: stay eager for this key
+                    graphs[key] = -1
+                    graphs.setdefault("errors", []).append(f"{key}: {type(exc).__name__}: {exc}")
+                    torch.cuda.synchronize()
+            elif entry >= 0:
+                graphs[key] = entry + 1
+        parts_dev.append(_step(loss_func, opt, data))
     if not parts_dev:
         return []
     parts = torch.stack(parts_dev).cpu().numpy()
@@ -123,6 +210,8 @@ class Basic_train:
         self.train_sphase = len(train_data)
         self.train_data, self.loss_func, self.opt, self.test, self.args = train_data, loss_func, opt, test, args
         self.early_stop = Early_stop(args, self.cfg)
+        # config["hip_graph"]: replay each phase's step as a captured HIP graph (needs Adam(capturable=True))
+        self.graphs = {} if self.cfg.get("hip_graph", False) else None
 
     def run(self, model, verbose=True):
         history = []
@@ -130,7 +219,7 @@ class Basic_train:
             model.train()
             for i in range(self.train_sphase):
                 start = time.time()
-                loss_list = epoch_training(self.train_data[i], self.loss_func[i], self.opt[i], verbose=verbose)
+                loss_list = epoch_training(self.train_data[i], self.loss_func[i], self.opt[i], verbose=verbose, graphs=self.graphs)
                 if verbose:
                     print(f"[Epoch:{ep}][Time:{(time.time() - start) / 60:.2}]:"
                           f"avg_loss_{i} :{sum(loss_list) / len(loss_list):.5}")

@@ -125,3 +125,65 @@ def test_predict_rating_cache_is_dropped_on_train():
     m.eval()
     r2 = m.predict_rating(users)
     assert not torch.equal(r1, r2)
+
+
+def test_capturable_adam_matches_adam():
+    """Adam(capturable=True) (step counter + bias corrections on the device) equals the host-stepped kernel."""
+    torch.manual_seed(0)
+    a = torch.randn(1000, 33, device=DEV).requires_grad_()
+    b = a.detach().clone().requires_grad_()
+    oa, ob = T.Adam([a], lr=0.01), T.Adam([b], lr=0.01, capturable=True)
+    for k in range(5):
+        g = torch.randn(1000, 33, device=DEV, generator=torch.Generator(device=DEV).manual_seed(k))
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=1e-6, atol=1e-8)
+    assert int(ob.state[id(b)]["t_dev"]) == 5
+
+
+@pytest.mark.parametrize("name", ["lightgcn", "ngcf", "tgcn"])
+def test_graphed_epoch_matches_eager(name):
+    """epoch_training(graphs={}) -- two eager steps, then every full-size batch a replay of ONE captured HIP graph --
+    gives the losses and parameters of the eager loop (float atomics in the BPR scatter aside)."""
+    ds = T.synth.make_cf_dataset(150, 120, 3000, seed=5, n_tag=30, n_assign=900)
+    kw = dict(dim_layer_list=[32, 32], dim_latent=32, device=DEV, train_batch=256, neighbor_k=5)
+    if name != "tgcn":
+        kw["use_tag"] = False
+    cfg = T.get_config(name, **kw)
+    cls = {"lightgcn": T.LightGCN, "ngcf": T.NGCF, "tgcn": T.TGCN}[name]
+    out = []
+    for use_graph in (False, True):
+        torch.manual_seed(3)
+        m = cls(ds, config=cfg)
+        m.train()
+        opt = T.Adam(m.parameters(), lr=0.01, capturable=use_graph)
+        prod = T.BPR_training_data(ds, config=cfg, seed=9)
+        graphs = {} if use_graph else None
+        losses = []
+        for _ in range(2):
+            losses += T.epoch_training(prod, m.loss, opt, verbose=False, graphs=graphs)
+        if use_graph:
+            assert not graphs.get("errors"), graphs.get("errors")
+            assert sum(isinstance(v, T.GraphedStep) for v in graphs.values()) == 1
+            assert opt.step_count == len(losses)
+        out.append((np.array(losses), {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}))
+    (l0, s0), (l1, s1) = out
+    assert len(l0) == len(l1) and len(l0) >= 16
+    np.testing.assert_allclose(l1, l0, rtol=2e-4)
+    for k in s0:
+        assert np.mean(np.abs(s1[k] - s0[k]) <= 1e-4) >= 0.99, k
+
+
+def test_basic_train_with_hip_graph_config(tmp_path):
+    ds = T.synth.make_cf_dataset(120, 90, 2500, seed=8)
+    cfg = T.get_config("lightgcn", use_tag=False, dim_layer_list=[32, 32], dim_latent=32, device=DEV, epochs=3,
+                       test_interval=2, train_batch=256, test_batch=50, hip_graph=True)
+    torch.manual_seed(1)
+    model = T.LightGCN(ds, config=cfg)
+    train = T.Basic_train([T.BPR_training_data(ds, config=cfg, seed=3)], [model.loss],
+                          [T.Adam(model.parameters(), lr=0.01, capturable=True)], T.Basic_test(ds, config=cfg),
+                          types.SimpleNamespace(out_dir=str(tmp_path)), config=cfg)
+    hist = train.run(model, verbose=False)
+    assert not train.graphs.get("errors"), train.graphs.get("errors")
+    assert any(isinstance(v, T.GraphedStep) for v in train.graphs.values())
+    assert np.mean(hist[-1][2]) < np.mean(hist[0][2])

@@ -11,16 +11,18 @@ for name, kw in (("lightgcn", dict(use_tag=False, dim_layer_list=[64, 64])),
                  ("ngcf", dict(use_tag=False, dim_layer_list=[64, 64])),
                  ("tgcn", dict(dim_layer_list=[64, 64], neighbor_k=25))):
     cfg = T.get_config(name, dim_latent=64, device=dev, train_batch=512, **kw)
-    torch.manual_seed(0)
-    model = {"lightgcn": T.LightGCN, "ngcf": T.NGCF, "tgcn": T.TGCN}[name](ds, config=cfg)
-    opt = T.Adam(model.parameters(), lr=0.01)
-    prod = T.BPR_training_data(ds, config=cfg, seed=1)
-    model.train()
-    T.epoch_training(prod, model.loss, opt)                      # warm-up epoch
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    losses = T.epoch_training(prod, model.loss, opt)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t
-    print(f"{name}: {len(losses)} steps/epoch, {dt / len(losses) * 1e3:.3f} ms/step (epoch_training, host floats per step), "
-          f"epoch {dt:.3f} s, loss {losses[-1]:.4f}", flush=True)
+    for graphs in (None, {}):
+        torch.manual_seed(0)
+        model = {"lightgcn": T.LightGCN, "ngcf": T.NGCF, "tgcn": T.TGCN}[name](ds, config=cfg)
+        opt = T.Adam(model.parameters(), lr=0.01, capturable=graphs is not None)
+        prod = T.BPR_training_data(ds, config=cfg, seed=1)
+        model.train()
+        T.epoch_training(prod, model.loss, opt, verbose=False, graphs=graphs)      # warm-up epoch (captures the graph)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        losses = T.epoch_training(prod, model.loss, opt, verbose=False, graphs=graphs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        mode = "eager" if graphs is None else ("HIP graph" if not graphs.get("errors") else f"graph FAILED {graphs['errors'][:1]}")
+        print(f"{name} [{mode}]: {len(losses)} steps/epoch, {dt / len(losses) * 1e3:.3f} ms/step, epoch {dt:.3f} s, "
+              f"loss {losses[-1]:.4f}", flush=True)
