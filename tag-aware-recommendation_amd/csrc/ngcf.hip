@@ -307,11 +307,15 @@ template <int DIN, int DOUT>
 int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float* dP2, int64_t n, float* dW1, float* dW2,
                  float* ws, hipStream_t s) {
   const int64_t steps = (n + 3) / 4;
-  const int64_t per = (steps + kWgradWaves - 1) / kWgradWaves;
-  ngcf_wgrad_kernel<DIN, DOUT><<<kWgradBlocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws);
+  int64_t per = (steps + kWgradWaves - 1) / kWgradWaves;
+  if (per < 8) per = 8;                 // small graphs: fewer waves, so the fold below walks fewer partials
+  constexpr int kWavesPerBlock = kNgcfThreads / 64;
+  const int64_t waves = steps > 0 ? (steps + per - 1) / per : 1;      // n == 0: one block writes zero partials
+  const unsigned blocks = static_cast<unsigned>((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+  ngcf_wgrad_kernel<DIN, DOUT><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws);
   TAGREC_LAUNCH_CHECK();
   const int elems = DIN * DOUT;
-  ngcf_wgrad_reduce_kernel<<<(2 * elems + 63) / 64, 256, 0, s>>>(ws, kWgradWaves, elems, dW1, dW2);
+  ngcf_wgrad_reduce_kernel<<<(2 * elems + 63) / 64, 256, 0, s>>>(ws, static_cast<int>(blocks) * kWavesPerBlock, elems, dW1, dW2);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

@@ -198,14 +198,24 @@ __global__ __launch_bounds__(kAttnThreads) void tgcn_attn_bwd_kernel(const float
   for (int i = threadIdx.x; i < (n_wt + 1) * A; i += kAttnThreads) o[i] = sh[i];
 }
 
-// fold the per-block partial tables in block order (deterministic given the partials)
-__global__ void tgcn_attn_fold_kernel(const float* __restrict__ part, int n_blocks, int elems, int split,
-                                      float* __restrict__ dWT, float* __restrict__ dv) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
+// fold the per-block partial tables: 16 threads per element take every 16th block, then a fixed-order combine
+// (deterministic given the partials; a single thread per element would walk up to 2048 dependent loads)
+__global__ __launch_bounds__(256) void tgcn_attn_fold_kernel(const float* __restrict__ part, int n_blocks, int elems, int split,
+                                                              float* __restrict__ dWT, float* __restrict__ dv) {
+  __shared__ float sh[16][16];
+  const int el = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
   float s = 0.f;
-  for (int b = 0; b < n_blocks; ++b) s += part[static_cast<int64_t>(b) * elems + e];
-  if (e < split) dWT[e] = s; else dv[e - split] = s;
+  if (e < elems)
+    for (int b = p; b < n_blocks; b += 16) s += part[static_cast<int64_t>(b) * elems + e];
+  sh[p][el] = s;
+  __syncthreads();
+  if (p == 0 && e < elems) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][el];
+    if (e < split) dWT[e] = t; else dv[e - split] = t;
+  }
 }
 
 }  // namespace tagrec
@@ -284,7 +294,7 @@ extern "C" int tagrec_tgcn_attn_bwd_f32(const float* P, const float* Q, const fl
   }
 #undef LAUNCH
   TAGREC_LAUNCH_CHECK();
-  tgcn_attn_fold_kernel<<<(elems + 255) / 256, 256, 0, s>>>(workspace, static_cast<int>(blocks), elems, n_wt * A, dWT, dv);
+  tgcn_attn_fold_kernel<<<(elems + 15) / 16, 256, 0, s>>>(workspace, static_cast<int>(blocks), elems, n_wt * A, dWT, dv);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
