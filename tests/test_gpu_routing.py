@@ -169,6 +169,43 @@ def test_edge_value_operators_on_a_non_symmetric_graph():
         np.testing.assert_allclose(t.grad.cpu().numpy(), w.cpu().numpy(), rtol=1e-3, atol=1e-4 * float(w.abs().max()))
 
 
+def test_routing_identities_at_scale():
+    """Size-independent properties on a graph the CPU oracle cannot finish in seconds (2 M nodes, 40 M entries, long rows
+    included): (1) the routed product with K = 1 and the graph's own values IS the plain product; (2) product and score pass
+    are adjoint: <H, A(w) T> = sum_j w_j <H[row_j], T[col_j]>, per factor; (3) A(w)^T via the permutation satisfies
+    <x, A(w) y> = <A(w)^T x, y>; (4) softmax weights sum to one per entry and the row scaling normalises row sums."""
+    ds = T.synth.make_bipartite_device(1_000_000, 1_000_000, 20_000_000, seed=4, device=DEV)
+    e = ds.edge_index["train"]
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 1_000_000, 1_000_000, "bi_norm")
+    g = T.Graph(rp, col, val, (n, n), symmetric=True)
+    rg = R.RoutingGraph(g)
+    assert g.info()["n_long_rows"] > 0
+    D, K = 64, 4
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(n, D, device=DEV, generator=gen)
+    h = torch.randn(n, D, device=DEV, generator=gen)
+    # (1)
+    y_plain = g.spmm(x)
+    y_routed, _, _ = rg.spmm(val.view(-1, 1), x)
+    assert float((y_routed - y_plain).abs().max()) <= 1e-5 * float(y_plain.abs().max())
+    # (2), (3), (4)
+    w = rg.softmax(torch.randn(rg.nnz, K, device=DEV, generator=gen))
+    assert float((w.sum(1) - 1).abs().max()) < 1e-5
+    y, _, _ = rg.spmm(w, x)
+    sc = torch.empty(rg.nnz, K, device=DEV)
+    rg.score(h, x, sc, accumulate=False)
+    lhs = (h.double() * y.double()).view(n, K, -1).sum((0, 2))
+    rhs = (w.double() * sc.double()).sum(0)
+    np.testing.assert_allclose(lhs.cpu().numpy(), rhs.cpu().numpy(), rtol=1e-6)
+    yt, _, _ = rg.spmm(w, h, transposed=True)
+    np.testing.assert_allclose(float((x.double() * yt.double()).sum()), float((h.double() * y.double()).sum()), rtol=1e-6)
+    d = rg.rowsum_rsqrt(w)
+    ones = torch.ones(n, D, device=DEV)
+    rs, _, _ = rg.spmm(w, ones)                                      # row sums of every factor, broadcast over its slice
+    nz = (rp[1:] > rp[:-1])
+    np.testing.assert_allclose((d[nz] ** 2 * rs.view(n, K, -1)[nz][:, :, 0]).cpu().numpy(), 1.0, rtol=1e-4)
+
+
 # ------------------------------------------------------------------ models against the reference's fixtures
 def _ds_from_fixture(fx):
     ds = T.synth.Dataset()
