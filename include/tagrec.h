@@ -217,6 +217,12 @@ int tagrec_ngcf_dense_fwd_f32(const float* N, const float* X, const float* W1p, 
 int tagrec_ngcf_dense_bwd_f32(const float* dXp, const float* N, const float* X, const float* W1p,
                               const float* W2p, int64_t n_rows, int Din, int Dout, float* dN, float* dXd,
                               float* dP1, float* dP2, void* stream);
+/* bwd with the normalize-backward folded in: the gradient w.r.t. Xp is G (may be NULL; what the next layer sent
+ * back) + normalize-backward(Xp, inv_norm, dZ), dZ = this layer's slot of the concat gradient, row stride ldz. */
+int tagrec_ngcf_dense_bwd_norm_f32(const float* G, const float* Xp, const float* inv_norm, const float* dZ, int64_t ldz,
+                                   const float* N, const float* X, const float* W1p, const float* W2p,
+                                   int64_t n_rows, int Din, int Dout, float* dN, float* dXd, float* dP1,
+                                   float* dP2, void* stream);
 int tagrec_ngcf_wgrad_f32(const float* N, const float* X, const float* dP1, const float* dP2, int64_t n_rows,
                           int Din, int Dout, float* dW1p, float* dW2p, float* workspace,
                           int64_t workspace_floats, void* stream);

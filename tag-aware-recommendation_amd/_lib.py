@@ -52,6 +52,8 @@ _SIGNATURES = {
                                   c_void_p, c_int64, c_void_p],
     "tagrec_ngcf_dense_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p],
+    "tagrec_ngcf_dense_bwd_norm_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_ngcf_wgrad_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_int64, c_void_p],
     "tagrec_tgcn_attn_workspace": [c_int, c_int],

@@ -141,8 +141,19 @@ __global__ __launch_bounds__(kNgcfThreads, 2) void ngcf_fwd_kernel(const float* 
 }
 
 // ---- backward, activation part: dN, dX_direct and the pre-activation gradients dP1, dP2 ----------
-template <int DIN, int DOUT>
-__global__ __launch_bounds__(kNgcfThreads) void ngcf_bwd_kernel(const float* __restrict__ dXp, const float* __restrict__ Nn,
+// The gradient w.r.t. Xp is either given (dXp) or formed here (NORM): dXp = G + normalize-backward(Xp, inv, dZ), G
+// (may be null) = what the NEXT layer sent back to this layer's output, dZ = this layer's slot of the concat
+// gradient (row stride ldz).  Forming it here saves writing and re-reading an [n, Dout] tensor per layer.
+struct NormGrad {
+  const float* Xp;
+  const float* inv;
+  const float* dZ;
+  int64_t ldz;
+};
+
+template <int DIN, int DOUT, bool NORM>
+__global__ __launch_bounds__(kNgcfThreads) void ngcf_bwd_kernel(const float* __restrict__ dXp, NormGrad ng,
+                                                                const float* __restrict__ Nn,
                                                                 const float* __restrict__ X, const float* __restrict__ W1,
                                                                 const float* __restrict__ W2, int64_t n_rows,
                                                                 float* __restrict__ dNn, float* __restrict__ dXd,
@@ -163,10 +174,38 @@ __global__ __launch_bounds__(kNgcfThreads) void ngcf_bwd_kernel(const float* __r
 #pragma unroll
     for (int ib = 0; ib < S::IB; ++ib) { a1[ib] = nn[ib] + x[ib]; a2[ib] = nn[ib] * x[ib]; }
     product_pair<DIN, DOUT>(lds, a1, a2, p1, p2, lane);      // recompute the pre-activations
+    f32x4 gx[S::MB];
 #pragma unroll
     for (int mb = 0; mb < S::MB; ++mb) {
-      f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok) g = *reinterpret_cast<const f32x4*>(dXp + row * DOUT + mb * 16 + q * 4);
+      gx[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok && dXp) gx[mb] = *reinterpret_cast<const f32x4*>(dXp + row * DOUT + mb * 16 + q * 4);
+    }
+    if constexpr (NORM) {
+      f32x4 z[S::MB], dz[S::MB];
+      const float inv = ok ? ng.inv[row] : 0.f;
+      float dot = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb) {
+        z[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dz[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          z[mb] = *reinterpret_cast<const f32x4*>(ng.Xp + row * DOUT + mb * 16 + q * 4) * inv;
+          dz[mb] = *reinterpret_cast<const f32x4*>(ng.dZ + row * ng.ldz + mb * 16 + q * 4);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dot = fmaf(z[mb][v], dz[mb][v], dot);
+      }
+      dot += __shfl_xor(dot, 16);
+      dot += __shfl_xor(dot, 32);
+      if (inv >= 1e12f) dot = 0.f;                         // the clamp is constant where ||Xp|| <= eps
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gx[mb][v] += inv * (dz[mb][v] - z[mb][v] * dot);
+    }
+#pragma unroll
+    for (int mb = 0; mb < S::MB; ++mb) {
+      const f32x4 g = gx[mb];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         p1[mb][v] = g[v] * lrelu_grad(p1[mb][v]);
@@ -254,20 +293,23 @@ __global__ __launch_bounds__(kNgcfThreads, 2) void ngcf_wgrad_kernel(const float
       }
 }
 
-// fold the per-wave partials in wave order: 4 threads per element take every 4th wave, then a fixed-order
-// combine -> deterministic and 4x the memory parallelism of one thread per element
-__global__ __launch_bounds__(256) void ngcf_wgrad_reduce_kernel(const float* __restrict__ slab, int n_waves, int elems,
-                                                                 float* __restrict__ dW1, float* __restrict__ dW2) {
-  __shared__ float sh[4][64];
+// fold the per-wave partials: 16 threads per element take every 16th wave, then a fixed-order combine ->
+// deterministic, and 16 independent load streams per element (at C3 the slab is 64 MB per layer)
+constexpr int kReduceParts = 16;
+__global__ __launch_bounds__(64 * kReduceParts) void ngcf_wgrad_reduce_kernel(const float* __restrict__ slab, int n_waves, int elems,
+                                                                             float* __restrict__ dW1, float* __restrict__ dW2) {
+  __shared__ float sh[kReduceParts][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   float s = 0.f;
   if (e < 2 * elems)
-    for (int w = part; w < n_waves; w += 4) s += slab[static_cast<int64_t>(w) * 2 * elems + e];
+    for (int w = part; w < n_waves; w += kReduceParts) s += slab[static_cast<int64_t>(w) * 2 * elems + e];
   sh[part][threadIdx.x & 63] = s;
   __syncthreads();
   if (part == 0 && e < 2 * elems) {
-    const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < kReduceParts; ++k) t += sh[k][threadIdx.x];
     if (e < elems) dW1[e] = t; else dW2[e - elems] = t;
   }
 }
@@ -288,17 +330,17 @@ int launch_fwd(const float* Nn, const float* X, const float* W1, const float* W2
 }
 
 template <int DIN, int DOUT>
-int launch_bwd(const float* dXp, const float* Nn, const float* X, const float* W1, const float* W2, int64_t n,
+int launch_bwd(const float* dXp, const NormGrad& ng, const float* Nn, const float* X, const float* W1, const float* W2, int64_t n,
                float* dNn, float* dXd, float* dP1, float* dP2, hipStream_t s) {
   using S = NgcfShape<DIN, DOUT>;
   const size_t lds = sizeof(float) * (2 * DIN * S::LDW + 2 * DOUT * S::LDT);
   const int64_t tiles = (n + 63) / 64;
   const unsigned grid = static_cast<unsigned>(tiles < 1024 ? tiles : 1024);
-  auto kern = ngcf_bwd_kernel<DIN, DOUT>;
+  auto kern = ng.Xp ? ngcf_bwd_kernel<DIN, DOUT, true> : ngcf_bwd_kernel<DIN, DOUT, false>;
   if (lds > 64 * 1024)
     TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds)));
-  kern<<<grid, kNgcfThreads, lds, s>>>(dXp, Nn, X, W1, W2, n, dNn, dXd, dP1, dP2);
+  kern<<<grid, kNgcfThreads, lds, s>>>(dXp, ng, Nn, X, W1, W2, n, dNn, dXd, dP1, dP2);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
@@ -315,7 +357,7 @@ int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float*
   ngcf_wgrad_kernel<DIN, DOUT><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws);
   TAGREC_LAUNCH_CHECK();
   const int elems = DIN * DOUT;
-  ngcf_wgrad_reduce_kernel<<<(2 * elems + 63) / 64, 256, 0, s>>>(ws, static_cast<int>(blocks) * kWavesPerBlock, elems, dW1, dW2);
+  ngcf_wgrad_reduce_kernel<<<(2 * elems + 63) / 64, 64 * kReduceParts, 0, s>>>(ws, static_cast<int>(blocks) * kWavesPerBlock, elems, dW1, dW2);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
@@ -365,7 +407,24 @@ extern "C" int tagrec_ngcf_dense_bwd_f32(const float* dXp, const float* Nn, cons
                      aligned16(dP2), "ngcf_dense_bwd: rows must be 16-byte aligned");
   if (n_rows == 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(A, B) launch_bwd<A, B>(dXp, Nn, X, W1p, W2p, n_rows, dNn, dXd, dP1, dP2, s)
+  const NormGrad ng{nullptr, nullptr, nullptr, 0};
+#define CALL(A, B) launch_bwd<A, B>(dXp, ng, Nn, X, W1p, W2p, n_rows, dNn, dXd, dP1, dP2, s)
+  TAGREC_NGCF_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int tagrec_ngcf_dense_bwd_norm_f32(const float* G, const float* Xp, const float* inv_norm, const float* dZ, int64_t ldz,
+                                              const float* Nn, const float* X, const float* W1p, const float* W2p,
+                                              int64_t n_rows, int Din, int Dout, float* dNn, float* dXd, float* dP1,
+                                              float* dP2, void* stream) {
+  TAGREC_REQUIRE(Xp && inv_norm && dZ && Nn && X && W1p && W2p && dNn && dXd && dP1 && dP2, "ngcf_dense_bwd_norm: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && ldz >= Dout && ldz % 4 == 0, "ngcf_dense_bwd_norm: bad shape");
+  TAGREC_REQUIRE(aligned16(G) && aligned16(Xp) && aligned16(dZ) && aligned16(Nn) && aligned16(X) && aligned16(dNn) &&
+                     aligned16(dXd) && aligned16(dP1) && aligned16(dP2), "ngcf_dense_bwd_norm: rows must be 16-byte aligned");
+  if (n_rows == 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const NormGrad ng{Xp, inv_norm, dZ, ldz};
+#define CALL(A, B) launch_bwd<A, B>(G, ng, Nn, X, W1p, W2p, n_rows, dNn, dXd, dP1, dP2, s)
   TAGREC_NGCF_DISPATCH(CALL);
 #undef CALL
 }

@@ -28,15 +28,24 @@ def dense_forward(nei, x, w1p, w2p, xp, inv, z_slot, ldz):
                                                      _lib.stream_ptr()), "ngcf_dense_fwd")
 
 
-def dense_backward(dxp, nei, x, w1p, w2p):
+def dense_backward(dxp, nei, x, w1p, w2p, norm=None):
+    """norm = (xp, inv, dz, ldz): the gradient w.r.t. Xp is dxp (may be None) + normalize-backward of the layer's slot
+    dz of the concat gradient, formed inside the kernel."""
     n, din = x.shape
     dout = w1p.shape[1]
     d_nei, d_xd = torch.empty_like(x), torch.empty_like(x)
     dp1, dp2 = torch.empty(n, dout, device=x.device), torch.empty(n, dout, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.tagrec_ngcf_dense_bwd_f32(_lib.ptr(dxp), _lib.ptr(nei), _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n,
-                                             din, dout, _lib.ptr(d_nei), _lib.ptr(d_xd), _lib.ptr(dp1), _lib.ptr(dp2),
-                                             _lib.stream_ptr()), "ngcf_dense_bwd")
+    if norm is not None:
+        xp, inv, dz, ldz = norm
+        _lib.check(lib.tagrec_ngcf_dense_bwd_norm_f32(_lib.ptr(dxp), _lib.ptr(xp), _lib.ptr(inv), _lib.ptr(dz), ldz, _lib.ptr(nei),
+                                                      _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n, din, dout, _lib.ptr(d_nei),
+                                                      _lib.ptr(d_xd), _lib.ptr(dp1), _lib.ptr(dp2), _lib.stream_ptr()),
+                   "ngcf_dense_bwd_norm")
+    else:
+        _lib.check(lib.tagrec_ngcf_dense_bwd_f32(_lib.ptr(dxp), _lib.ptr(nei), _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n,
+                                                 din, dout, _lib.ptr(d_nei), _lib.ptr(d_xd), _lib.ptr(dp1), _lib.ptr(dp2),
+                                                 _lib.stream_ptr()), "ngcf_dense_bwd")
     ws_n = lib.tagrec_ngcf_wgrad_workspace(din, dout)
     ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
     dw1, dw2 = torch.empty_like(w1p), torch.empty_like(w2p)
@@ -74,11 +83,8 @@ def propagate_backward(graph_t, d_out, saved, dims):
     dx_next = None
     for k in range(len(saved) - 1, -1, -1):
         x, nei, xp, inv, w1p, w2p = saved[k]
-        dxp = dx_next if dx_next is not None else torch.empty_like(xp)
-        _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(xp), _lib.ptr(inv), _lib.ptr(d_out[:, offs[k + 1]:]), dtot, 1.0,
-                                              _lib.ptr(dxp), 1 if dx_next is not None else 0, n, dims[k + 1],
-                                              _lib.stream_ptr()), "rownorm_bwd")
-        d_nei, d_xd, dw1, dw2 = dense_backward(dxp, nei, x, w1p, w2p)
+        # d Xp = (what layer k+1 sent back) + normalize-backward of this layer's concat slot, formed inside the kernel
+        d_nei, d_xd, dw1, dw2 = dense_backward(dx_next, nei, x, w1p, w2p, norm=(xp, inv, d_out[:, offs[k + 1]:], dtot))
         dws[k] = (dw1, dw2)
         dx = torch.empty_like(x)
         graph_t.spmm_axpy(d_nei, d_xd, 1.0, dx)
