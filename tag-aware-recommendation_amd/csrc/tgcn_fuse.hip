@@ -256,10 +256,142 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_fwd_kernel(
   }
 }
 
+// ---- forward, fusion weights staged through LDS --------------------------------------------------------------
+// In the kernel above every wave streams the whole of Wf (32 D + 48 rows of Dout floats) from L2 for its 16 nodes;
+// with the weight loads removed it runs twice as fast (measured at D = Dout = 128), i.e. it is bound by that stream.
+// Here the block's four waves -- four 16-node subtiles walking the same weight rows in the same order -- share
+// each 32-row chunk of Wf through LDS: the L2 stream shrinks 4x.  Chunks are filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, the kernel is at the VGPR limit for two waves per SIMD), two
+// buffers, chunk i+1 in flight while chunk i feeds the MFMAs, one barrier per chunk.
+//   chunk (c, ec): rows k = c D + q D/4 + ec*kEC + el  (q < 4, el < kEC)  ->  LDS row q*kEC + el
+//   a DMA wave-instruction writes 1 KiB = kRP consecutive LDS rows (one q); piece p sits at p*1024 + q*32 + (q&1)*SHIFT
+//   bytes: with Dout = 128 the 16-byte shift of odd q makes the two quarters a ds_read_b128 lane group spans
+//   (q = 0,1 or q = 2,3) fall on disjoint banks; with Dout = 64 they already do.
+constexpr int kEC = 8;
+
+template <int D, int DOUT, int A>
+__global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_fwd_lds_kernel(
+    const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, int64_t n,
+    const float* __restrict__ U, const float* __restrict__ qv, const float* __restrict__ pv,
+    const float* __restrict__ wb, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ w3, const float* __restrict__ Wf, const float* __restrict__ bf,
+    float* __restrict__ bw_out, float* __restrict__ out) {
+  constexpr int DS = D / 4, OS = DOUT / 4, OB = DOUT / 16, AB = A / 16;
+  constexpr int NEC = DS / kEC;                         // chunks per bit-level filter
+  constexpr int RP = 256 / DOUT;                        // LDS rows per 1 KiB piece
+  constexpr int PIECES = 4 * kEC / RP, PPW = PIECES / 4;   // per chunk, per wave
+  constexpr int SHIFT = DOUT == 128 ? 16 : 0;
+  constexpr int BUF_BYTES = PIECES * 1024 + 3 * 32 + 32;
+  static_assert(NEC >= 2 && NEC % 2 == 0 && kEC % RP == 0 && PPW >= 1, "tgcn_fuse_fwd_lds: unsupported shape");
+  __shared__ __attribute__((aligned(1024))) char wbuf[2][BUF_BYTES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_groups = (n + 63) / 64;
+  const float* Tj[3] = {T0, T1, T2};
+  // DMA source of this lane inside a chunk: piece p = wave*PPW + j covers LDS rows p*RP ..; the lane's row / column
+  const int lanes_per_row = DOUT / 4;
+  const int row_in_piece = lane / lanes_per_row, c4 = lane % lanes_per_row;
+  // this lane's read base inside a buffer (see the layout above)
+  const int read_base = q * (kEC / RP) * 1024 + q * 32 + (q & 1) * SHIFT + r * OB * 4;
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    U = fresh(U); qv = fresh(qv); pv = fresh(pv); wb = fresh(wb); w1 = fresh(w1); w2 = fresh(w2); w3 = fresh(w3);
+    Wf = fresh(Wf); bf = fresh(bf);
+    auto issue = [&](int c, int ec, int buf) {
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        const int p = wave * PPW + j;
+        const int lrow = p * RP + row_in_piece;            // LDS row -> (q', el)
+        const int qq = lrow / kEC, el = lrow % kEC;
+        const float* src = Wf + (static_cast<int64_t>(c) * D + qq * DS + ec * kEC + el) * DOUT + c4 * 4;
+        const int pq = (p * RP) / kEC;
+        char* dst = &wbuf[buf][p * 1024 + pq * 32 + (pq & 1) * SHIFT];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+    issue(0, 0, 0);
+    float t[3][DS];
+    const int64_t node = (grp * 4 + wave) * 16 + r;
+    const bool ok = node < n;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) load_seg<DS>(Tj[j] + node * D + q * DS, ok, t[j]);
+    {
+      f32x4 sc[3][AB];
+      float bw[3];
+      type_attention<D, A>(t, U, qv, pv, r, q, sc, bw);
+      if (ok && q == 0) {
+        bw_out[node * 3 + 0] = bw[0];
+        bw_out[node * 3 + 1] = bw[1];
+        bw_out[node * 3 + 2] = bw[2];
+      }
+    }
+    f32x4 acc[OB];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) acc[ob] = zero4();
+    for (int c = 0; c < kBitC; ++c) {
+      const float c0 = wb[c * 3], c1 = wb[c * 3 + 1], c2 = wb[c * 3 + 2];
+#pragma unroll
+      for (int ec = 0; ec < NEC; ++ec) {
+        __syncthreads();                                 // chunk (c, ec) has landed; the other buffer is free again
+        if (ec + 1 < NEC) issue(c, ec + 1, (ec + 1) & 1);
+        else if (c + 1 < kBitC) issue(c + 1, 0, 0);
+        const char* rb = &wbuf[ec & 1][read_base];
+#pragma unroll
+        for (int el = 0; el < kEC; ++el) {
+          float a[OB];
+          const float* ap = reinterpret_cast<const float*>(rb + (el / RP) * 1024 + (el % RP) * DOUT * 4);
+#pragma unroll
+          for (int i = 0; i < OB; i += 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(ap + i);
+            a[i] = w4.x; a[i + 1] = w4.y; a[i + 2] = w4.z; a[i + 3] = w4.w;
+          }
+          const int e = ec * kEC + el;
+          const float y = fmaxf(fmaf(c0, t[0][e], fmaf(c1, t[1][e], c2 * t[2][e])), 0.f);
+#pragma unroll
+          for (int ob = 0; ob < OB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob], y, acc[ob], 0, 0, 0);
+        }
+      }
+    }
+    {
+      f32x4 pre[6];
+      vector_conv<D>(t, w1, w2, w3, r, q, pre);
+#pragma unroll
+      for (int g = 0; g < 6; ++g)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int f = vec_feature(g, 4 * (q & 1) + v);
+          float a[OB];
+          load_run<OB>(Wf + (static_cast<int64_t>(kBitC) * D + f) * DOUT + r * OB, a);
+          const float y = q < 2 ? fmaxf(pre[g][v], 0.f) : 0.f;
+#pragma unroll
+          for (int ob = 0; ob < OB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob], y, acc[ob], 0, 0, 0);
+        }
+    }
+    if (ok) {
+      float o[OS];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[v * OB + ob] = fmaxf(acc[ob][v] + bf[q * OS + v * OB + ob], 0.f);
+      float* dst = out + node * DOUT + q * OS;
+#pragma unroll
+      for (int i = 0; i < OS; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+    }
+    __syncthreads();     // the next group's first DMA reuses buffer 0, which the last chunk's predecessor... keep it simple
+  }
+}
+
 template <int D, int DOUT>
 int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n, const float* U, const float* qv,
                     const float* pv, const float* wb, const float* w1, const float* w2, const float* w3, const float* Wf,
                     const float* bf, float* bw_out, float* out, hipStream_t s) {
+  if constexpr ((D == 64 || D == 128) && (DOUT == 64 || DOUT == 128)) {
+    const int64_t groups = (n + 63) / 64;
+    tgcn_fuse_fwd_lds_kernel<D, DOUT, 32><<<static_cast<unsigned>(groups < 512 ? groups : 512), kFuseThreads, 0, s>>>(
+        T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out);
+    TAGREC_LAUNCH_CHECK();
+    return TAGREC_OK;
+  }
   constexpr int NS = (D >= 64) ? 1 : 2;   // measured at D = 128: two waves per SIMD with one subtile beat one wave with two
   const int64_t tiles = (n + 16 * NS - 1) / (16 * NS);
   int64_t blocks = (tiles + 3) / 4;

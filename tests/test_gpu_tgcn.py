@@ -145,7 +145,8 @@ def test_neighbor_tables_semantics():
     assert wts_ut.max() >= 1 and (wts_ut[ids_ut == 0] == 0).all()
 
 
-@pytest.mark.parametrize("D,Dout,n", [(16, 16, 100), (64, 32, 333), (128, 128, 257), (32, 64, 64), (64, 64, 31)])
+@pytest.mark.parametrize("D,Dout,n", [(16, 16, 100), (64, 32, 333), (128, 128, 257), (32, 64, 64), (64, 64, 31), (128, 64, 700),
+                                      (64, 128, 40000)])
 def test_fused_dense_block_vs_operator_form(D, Dout, n):
     """csrc/tgcn_fuse.hip (type attention + convolutions + fusion in one kernel) against the same block
     written operator by operator (fp64 on the host); ragged node counts; gradients through autograd."""
