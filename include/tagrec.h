@@ -78,6 +78,20 @@ int tagrec_spmm_normbwd_f32(const tagrec_graph* g, const float* G_in, const floa
 int tagrec_spmm_axpy_f32(const tagrec_graph* g, const float* G_in, const float* B, float b_scale,
                          float* G_out, int D, void* stream);
 
+/* The forward / backward LightGCN layers with MESSAGE DROPOUT (F.dropout on the product, model/lightgcn.py:56) inside
+ * the epilogue: Y_raw = mask * (A @ X) / (1 - p) before it is normalised and accumulated; in the backward layer the
+ * same mask multiplies the gradient that leaves the layer.  Whether element i survives is a pure function of
+ * (seed, i) (counter-based generator, csrc/common.h), so nothing is stored between the passes; the caller uses one
+ * seed per layer and step.  tagrec_dropout_f32 applies the identical mask to a plain [n] buffer (n % 4 == 0): the
+ * last layer's normalize-backward, NGCF / TGCN layer outputs, tests.  Training-mode parity with the reference is
+ * statistical (it draws torch's generator). */
+int tagrec_spmm_norm_acc_drop_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
+                                  float* acc, float acc_scale, float drop_p, uint64_t seed, int D, void* stream);
+int tagrec_spmm_normbwd_drop_f32(const tagrec_graph* g, const float* G_in, const float* X_raw,
+                                 const float* inv_norm, const float* dZ, float d_scale, float drop_p,
+                                 uint64_t seed, float* G_out, int D, void* stream);
+int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream);
+
 /* ---- column-sharded tables (feature sharding over GPUs: every rank holds D/G columns of every row) ---------------
  * Whatever reduces over a row's columns is split into a local part, an all-reduce done by the caller, and an apply:
  *   spmm_ss          : Y = A @ X;  ss[r] = sum_c Y[r,c]^2 over the local columns

@@ -77,6 +77,11 @@ _SIGNATURES = {
     "tagrec_slice_norm_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "tagrec_row_softmax_fwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_row_softmax_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tagrec_spmm_norm_acc_drop_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, ctypes.c_uint64, c_int,
+                                      c_void_p],
+    "tagrec_spmm_normbwd_drop_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, ctypes.c_uint64, c_void_p,
+                                     c_int, c_void_p],
+    "tagrec_dropout_f32": [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p],
     "tagrec_eval_topk_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                              c_void_p, c_void_p],
     "tagrec_sample_negative_i64": [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, ctypes.c_uint64, c_void_p, c_void_p],

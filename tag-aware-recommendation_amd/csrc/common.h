@@ -33,4 +33,30 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 constexpr int kWave = 64;
 
+// splitmix64 finaliser: the counter-based generator behind the negative sampler and the dropout masks
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// Message dropout (F.dropout on a layer's output, /root/reference/model/lightgcn.py:56): whether element `index` of
+// the tensor drawn under `seed` survives is a pure function of (seed, index), so the backward pass re-creates the
+// forward's mask instead of storing it.  Four consecutive elements (one float4) share one hash: 4 x 16 bits.
+struct DropMask {
+  float p;          // drop probability; 0 = off
+  uint64_t seed;
+};
+__device__ __forceinline__ void drop4(const DropMask& m, int64_t float4_index, float& a, float& b, float& c, float& d) {
+  if (m.p <= 0.f) return;
+  const uint64_t h = mix64(m.seed ^ mix64(static_cast<uint64_t>(float4_index)));
+  const unsigned thr = static_cast<unsigned>(m.p * 65536.0f);          // keep iff 16-bit draw >= p * 2^16
+  const float keep = 1.0f / (1.0f - m.p);
+  a = ((h >> 0) & 0xFFFFu) >= thr ? a * keep : 0.f;
+  b = ((h >> 16) & 0xFFFFu) >= thr ? b * keep : 0.f;
+  c = ((h >> 32) & 0xFFFFu) >= thr ? c * keep : 0.f;
+  d = ((h >> 48) & 0xFFFFu) >= thr ? d * keep : 0.f;
+}
+
 }  // namespace tagrec

@@ -239,13 +239,6 @@ __global__ __launch_bounds__(kThreads) void bpr_bwd_kernel(const float* __restri
 // [0, n_right) per positive row, re-drawn while (left id, draw) is a positive pair.  The positives of a left id are
 // the sorted row `cols[rowptr[l] .. rowptr[l+1])`, so membership is a binary search in that row.  Counter-based
 // generator: draw t of row e under `seed` is a pure function of (seed, e, t) -- reproducible, order-free.
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {          // splitmix64 finaliser
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
 __global__ __launch_bounds__(kThreads) void sample_negative_kernel(const int64_t* __restrict__ left, int64_t n_rows,
                                                                    const int64_t* __restrict__ rowptr,
                                                                    const int32_t* __restrict__ cols, int64_t n_right,
@@ -373,6 +366,17 @@ __global__ __launch_bounds__(kThreads) void adam_tail_kernel(float* __restrict__
   m[i] = mi;
   v[i] = vi;
   p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+}
+
+// out = mask(seed) * x / (1 - p), the mask of common.h's DropMask (x may alias out)
+__global__ __launch_bounds__(kThreads) void dropout_kernel(const float4* __restrict__ x, float4* __restrict__ out, int64_t n4,
+                                                           DropMask m) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
+    float4 v = x[i];
+    drop4(m, i, v.x, v.y, v.z, v.w);
+    out[i] = v;
+  }
 }
 
 // step counter and the two step-dependent factors of Adam, advanced ON the device so a captured graph replays correctly
@@ -575,4 +579,17 @@ extern "C" int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* 
   TAGREC_LAUNCH_CHECK();
   if (n == 0) return TAGREC_OK;
   return launch_adam(p, g, m, v, n, b1, b2, eps, 0.f, 1.f, coef_dev, s);
+}
+
+extern "C" int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream) {
+  TAGREC_REQUIRE(x && out, "dropout: null pointer");
+  TAGREC_REQUIRE(n >= 0 && n % 4 == 0 && aligned16(x) && aligned16(out), "dropout: need a multiple of 4 elements, 16-byte aligned");
+  TAGREC_REQUIRE(p >= 0.f && p < 1.f, "dropout: p must be in [0, 1)");
+  if (n == 0) return TAGREC_OK;
+  int64_t blocks = (n / 4 + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  dropout_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+      reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), n / 4, DropMask{p, seed});
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
 }

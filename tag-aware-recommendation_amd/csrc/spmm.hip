@@ -36,6 +36,8 @@ struct EpiArgs {
   const float* B;         // NORMBWD / NORMBWD_DOT: dZ ; AXPY: B
   const float* dot;       // NORMBWD_DOT: z . (s dZ) per row, summed over ALL column shards by the caller
   float s;
+  DropMask drop;          // NORM_ACC: message dropout of the product before it is stored / normalised (lightgcn.py:56);
+                          // NORMBWD: the same mask on the gradient leaving this layer.  p = 0: off
 };
 
 // Streamed-once data (indices, values, epilogue operands, outputs) is moved with non-temporal accesses so it does
@@ -130,6 +132,7 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
   if constexpr (EPI == EPI_NONE) {
     if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
   } else if constexpr (EPI == EPI_NORM_ACC) {
+    drop4(e.drop, off, acc.x, acc.y, acc.z, acc.w);
     const float ss = group_sum<LPR>(f4_dot(acc, acc));
     const float den = fmaxf(sqrtf(ss), 1e-12f);
     if (writer) {
@@ -147,8 +150,9 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
     float4 dz = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
     dz.x *= e.s; dz.y *= e.s; dz.z *= e.s; dz.w *= e.s;
     const float4 gz = normalize_bwd<LPR>(xr, e.inv_norm[r], dz);
-    if (writer)
-      st_stream(reinterpret_cast<float4*>(e.Y) + off, make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w));
+    float4 o = make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w);
+    drop4(e.drop, off, o.x, o.y, o.z, o.w);
+    if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, o);
   } else if constexpr (EPI == EPI_AXPY) {
     const float4 b = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
     if (writer)
@@ -459,6 +463,7 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
   if (e.accum) vec_ok = vec_ok && aligned16(e.accum);
   if (e.Xraw) vec_ok = vec_ok && aligned16(e.Xraw);
   if (e.B) vec_ok = vec_ok && aligned16(e.B);
+  if (e.drop.p > 0.f && !vec_ok) return fail(TAGREC_E_INVALID, std::string(who) + ": dropout needs 16-byte aligned rows");
   if (vec_ok) {
     switch (D) {
       case 8: return launch_vec<2, EPI>(g, X, e, s);
@@ -482,14 +487,14 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
 }  // namespace
 
 extern "C" int tagrec_spmm_f32(const tagrec_graph* g, const float* X, float* Y, int D, void* stream) {
-  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
+  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}};
   return launch_spmm<EPI_NONE>(g, X, e, D, stream, "spmm");
 }
 
 extern "C" int tagrec_spmm_norm_acc_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
                                         float* acc, float acc_scale, int D, void* stream) {
   TAGREC_REQUIRE(inv_norm != nullptr && acc != nullptr, "spmm_norm_acc: null inv_norm or acc");
-  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale};
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{0.f, 0}};
   return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc");
 }
 
@@ -497,20 +502,20 @@ extern "C" int tagrec_spmm_normbwd_f32(const tagrec_graph* g, const float* G_in,
                                        const float* inv_norm, const float* dZ, float d_scale, float* G_out,
                                        int D, void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr, "spmm_normbwd: null X_raw, inv_norm or dZ");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{0.f, 0}};
   return launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd");
 }
 
 extern "C" int tagrec_spmm_axpy_f32(const tagrec_graph* g, const float* G_in, const float* B, float b_scale,
                                     float* G_out, int D, void* stream) {
   TAGREC_REQUIRE(B != nullptr, "spmm_axpy: null B");
-  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale};
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy");
 }
 
 extern "C" int tagrec_spmm_ss_f32(const tagrec_graph* g, const float* X, float* Y, float* ss, int D, void* stream) {
   TAGREC_REQUIRE(ss != nullptr, "spmm_ss: null ss");
-  EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f};
+  EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}};
   return launch_spmm<EPI_SS>(g, X, e, D, stream, "spmm_ss");
 }
 
@@ -519,6 +524,27 @@ extern "C" int tagrec_spmm_normbwd_dot_f32(const tagrec_graph* g, const float* G
                                            float* G_out, int D, void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr && dot != nullptr,
                  "spmm_normbwd_dot: null X_raw, inv_norm, dZ or dot");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}};
   return launch_spmm<EPI_NORMBWD_DOT>(g, G_in, e, D, stream, "spmm_normbwd_dot");
+}
+
+extern "C" int tagrec_spmm_norm_acc_drop_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
+                                             float* acc, float acc_scale, float drop_p, uint64_t seed, int D, void* stream) {
+  TAGREC_REQUIRE(inv_norm != nullptr && acc != nullptr, "spmm_norm_acc_drop: null inv_norm or acc");
+  TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_norm_acc_drop: p must be in [0, 1)");
+  TAGREC_REQUIRE(drop_p == 0.f || (D % 4 == 0 && D <= 256 && (D & (D - 1)) == 0 && D >= 8),
+                 "spmm_norm_acc_drop: dropout needs a vector-kernel width (8..256, power of two)");
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}};
+  return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc_drop");
+}
+
+extern "C" int tagrec_spmm_normbwd_drop_f32(const tagrec_graph* g, const float* G_in, const float* X_raw,
+                                            const float* inv_norm, const float* dZ, float d_scale, float drop_p,
+                                            uint64_t seed, float* G_out, int D, void* stream) {
+  TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr, "spmm_normbwd_drop: null X_raw, inv_norm or dZ");
+  TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_normbwd_drop: p must be in [0, 1)");
+  TAGREC_REQUIRE(drop_p == 0.f || (D % 4 == 0 && D <= 256 && (D & (D - 1)) == 0 && D >= 8),
+                 "spmm_normbwd_drop: dropout needs a vector-kernel width (8..256, power of two)");
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}};
+  return launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd_drop");
 }

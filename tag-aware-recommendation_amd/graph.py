@@ -246,21 +246,31 @@ class Graph:
         self._call("spmm", _lib.load().tagrec_spmm_f32, self._h, _lib.ptr(X), _lib.ptr(out), D, _lib.stream_ptr())
         return out
 
-    def spmm_norm_acc(self, X, y_raw, inv_norm, acc, acc_scale):
+    def spmm_norm_acc(self, X, y_raw, inv_norm, acc, acc_scale, drop_p=0.0, seed=0):
+        """drop_p > 0: message dropout of the product inside the epilogue (mask = f(seed, element))."""
         D = self._chk_x(X, self.shape[1], "spmm_norm_acc X")
         self._chk_x(y_raw, self.shape[0], "spmm_norm_acc y_raw")
         self._chk_x(acc, self.shape[0], "spmm_norm_acc acc")
         _lib.require_gpu_tensor(inv_norm, torch.float32, "inv_norm")
         if inv_norm.numel() != self.shape[0] or acc.shape[1] != D or y_raw.shape[1] != D:
             raise _lib.TagrecError("spmm_norm_acc: shape mismatch")
+        if drop_p > 0:
+            self._call("spmm_norm_acc", _lib.load().tagrec_spmm_norm_acc_drop_f32, self._h, _lib.ptr(X), _lib.ptr(y_raw),
+                       _lib.ptr(inv_norm), _lib.ptr(acc), float(acc_scale), float(drop_p), int(seed), D, _lib.stream_ptr())
+            return
         self._call("spmm_norm_acc", _lib.load().tagrec_spmm_norm_acc_f32, self._h, _lib.ptr(X), _lib.ptr(y_raw),
                    _lib.ptr(inv_norm), _lib.ptr(acc), float(acc_scale), D, _lib.stream_ptr())
 
-    def spmm_normbwd(self, g_in, x_raw, inv_norm, dz, d_scale, g_out):
+    def spmm_normbwd(self, g_in, x_raw, inv_norm, dz, d_scale, g_out, drop_p=0.0, seed=0):
         D = self._chk_x(g_in, self.shape[1], "spmm_normbwd g_in")
         for t, nm in ((x_raw, "x_raw"), (dz, "dz"), (g_out, "g_out")):
             if self._chk_x(t, self.shape[0], "spmm_normbwd " + nm) != D:
                 raise _lib.TagrecError("spmm_normbwd: width mismatch on " + nm)
+        if drop_p > 0:
+            self._call("spmm_normbwd", _lib.load().tagrec_spmm_normbwd_drop_f32, self._h, _lib.ptr(g_in), _lib.ptr(x_raw),
+                       _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), float(drop_p), int(seed), _lib.ptr(g_out), D,
+                       _lib.stream_ptr())
+            return
         self._call("spmm_normbwd", _lib.load().tagrec_spmm_normbwd_f32, self._h, _lib.ptr(g_in), _lib.ptr(x_raw),
                    _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), _lib.ptr(g_out), D, _lib.stream_ptr())
 

@@ -205,6 +205,18 @@ def transe_loss(head_e, rela_e, pos_tail_e, neg_tail_e):
     return torch.nn.functional.softplus(ps - ns).mean()
 
 
+def message_drop(x, p, seed, out=None):
+    """mask(seed) * x / (1 - p) with the library's counter-based mask (the one the fused layer kernels apply);
+    p = 0 returns x."""
+    if p <= 0:
+        return x
+    x = x.contiguous()
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.load().tagrec_dropout_f32(_lib.ptr(x), _lib.ptr(out), x.numel(), float(p), int(seed), _lib.stream_ptr()),
+               "dropout")
+    return out
+
+
 def node_drop(graph, keep_prob, training=False):
     """Edge dropout (adj.py:170-191).  As in the reference the argument called
     `keep_prob` is the DROP rate: an edge survives iff int(rand + (1-drop)) != 0

@@ -21,26 +21,33 @@ from .config import CFG as _GLOBAL_CFG
 from .graph import Graph, creat_adj
 
 
-def propagate_forward(graph, x0, n_layer):
-    """x0 -> (out, raws, invs): out = mean(x0, z1..zL), raws[k] = A^(k+1) x0 (un-normalised),
-    invs[k][r] = 1/max(||raws[k][r]||, 1e-12).  One fused kernel per layer."""
+def _layer_seed(seed, k):
+    return (int(seed) * 64 + k) & 0xFFFFFFFFFFFFFFFF
+
+
+def propagate_forward(graph, x0, n_layer, drops=None, seed=0):
+    """x0 -> (out, raws, invs): out = mean(x0, z1..zL), raws[k] = dropout(A raws[k-1]) (un-normalised),
+    invs[k][r] = 1/max(||raws[k][r]||, 1e-12).  One fused kernel per layer.  drops[k] > 0 = message dropout of
+    layer k's product (lightgcn.py:56), drawn inside the kernel from (seed, layer, element)."""
     s = 1.0 / (n_layer + 1)
     out = x0 * s
     raws, invs = [], []
     x = x0
-    for _ in range(n_layer):
+    for k in range(n_layer):
         y = torch.empty_like(x0)
         inv = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
-        graph.spmm_norm_acc(x, y, inv, out, s)
+        graph.spmm_norm_acc(x, y, inv, out, s, drops[k] if drops else 0.0, _layer_seed(seed, k))
         raws.append(y)
         invs.append(inv)
         x = y
     return out, raws, invs
 
 
-def propagate_backward(graph_t, d_out, raws, invs):
+def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0):
     """Gradient of `propagate_forward` w.r.t. x0 given d_out (dense [N,D]).
-    G^L = nb(X^L);  G^k = A^T G^(k+1) + nb(X^k);  G^0 = A^T G^1 + s*d_out,  nb = normalise-backward of s*d_out."""
+    G^L = nb(X^L);  G^k = A^T G^(k+1) + nb(X^k);  G^0 = A^T G^1 + s*d_out,  nb = normalise-backward of s*d_out.
+    With dropout each G^k (k >= 1) is multiplied by layer k's mask / (1 - p) before it travels on (it is the gradient
+    w.r.t. the product the mask was applied to)."""
     L = len(raws)
     s = 1.0 / (L + 1)
     if L == 0:
@@ -50,9 +57,11 @@ def propagate_backward(graph_t, d_out, raws, invs):
     g = torch.empty_like(d_out)
     _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(raws[L - 1]), _lib.ptr(invs[L - 1]), _lib.ptr(d_out), D, s,
                                           _lib.ptr(g), 0, n, D, _lib.stream_ptr()), "rownorm_bwd")
+    if drops and drops[L - 1] > 0:
+        H.message_drop(g, drops[L - 1], _layer_seed(seed, L - 1), out=g)
     for k in range(L - 2, -1, -1):
         gn = torch.empty_like(d_out)
-        graph_t.spmm_normbwd(g, raws[k], invs[k], d_out, s, gn)
+        graph_t.spmm_normbwd(g, raws[k], invs[k], d_out, s, gn, drops[k] if drops else 0.0, _layer_seed(seed, k))
         g = gn
     g0 = torch.empty_like(d_out)
     graph_t.spmm_axpy(g, d_out, s, g0)
@@ -61,25 +70,26 @@ def propagate_backward(graph_t, d_out, raws, invs):
 
 class _Propagate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, graph, n_layer):
-        out, raws, invs = propagate_forward(graph, table.detach(), n_layer)
-        ctx.graph, ctx.raws, ctx.invs = graph, raws, invs
+    def forward(ctx, table, graph, n_layer, drops=None, seed=0):
+        out, raws, invs = propagate_forward(graph, table.detach(), n_layer, drops, seed)
+        ctx.graph, ctx.raws, ctx.invs, ctx.drops, ctx.seed = graph, raws, invs, drops, seed
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        g0 = propagate_backward(ctx.graph.transpose(), d_out.contiguous(), ctx.raws, ctx.invs)
+        g0 = propagate_backward(ctx.graph.transpose(), d_out.contiguous(), ctx.raws, ctx.invs, ctx.drops, ctx.seed)
         ctx.raws = ctx.invs = None
-        return g0, None, None
+        return g0, None, None, None, None
 
 
 class _PropagateBprLoss(torch.autograd.Function):
     """table -> [mul_loss, l2reg_loss(ego rows)] in one autograd node."""
 
     @staticmethod
-    def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active):
+    def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active, drops=None, seed=0):
         x0 = table.detach()
-        out, raws, invs = propagate_forward(graph, x0, n_layer)
+        out, raws, invs = propagate_forward(graph, x0, n_layer, drops, seed)
+        ctx.drops, ctx.seed = drops, seed
         B, D = trip.shape[0], x0.shape[1]
         coef = torch.empty(B, dtype=torch.float32, device=x0.device)
         partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=x0.device)
@@ -107,7 +117,7 @@ class _PropagateBprLoss(torch.autograd.Function):
                                           _lib.ptr(ctx.coef), _lib.ptr(g), 1.0,
                                           _lib.ptr(d_out[:nu]), _lib.ptr(d_out[nu:nu + ni]), null, null,
                                           _lib.stream_ptr()), "bpr_bwd")
-        g0 = propagate_backward(ctx.graph.transpose(), d_out, ctx.raws, ctx.invs)
+        g0 = propagate_backward(ctx.graph.transpose(), d_out, ctx.raws, ctx.invs, ctx.drops, ctx.seed)
         # L2 term on the ego rows: added after the propagation hop has written g0
         if ctx.reg_active:
             Ue, Ie = x0[:nu], x0[nu:nu + ni]
@@ -116,7 +126,7 @@ class _PropagateBprLoss(torch.autograd.Function):
                                               null, null, _lib.ptr(g0[:nu]), _lib.ptr(g0[nu:nu + ni]),
                                               _lib.stream_ptr()), "bpr_bwd(reg)")
         ctx.raws = ctx.invs = ctx.out = None
-        return g0, None, None, None, None, None, None, None
+        return g0, None, None, None, None, None, None, None, None, None
 
 
 class LightGCN(TableModel):
@@ -138,10 +148,24 @@ class LightGCN(TableModel):
         self.use_tag = config["use_tag"]
         self.message_drop_list = config["message_drop_list"]
         self.node_drop = config["node_drop"]
+        self.drop_seed = config.get("seed", 2020)
 
     def _fused_ok(self):
-        drop = self.training and any(p > 0 for p in self.message_drop_list[:self.num_layer])
-        return isinstance(self.norm_adj, Graph) and not drop
+        return isinstance(self.norm_adj, Graph)
+
+    def _drops(self):
+        """(per-layer drop rates, seed of this forward pass) when message dropout is active, else (None, 0).  The
+        seed advances with every training-mode forward pass; masks are functions of (seed, layer, element)."""
+        drops = [float(p) for p in self.message_drop_list[:self.num_layer]]
+        if not (self.training and any(p > 0 for p in drops)):
+            return None, 0
+        if self.dim_latent % 4 or self.dim_latent > 256 or self.dim_latent & (self.dim_latent - 1) or self.dim_latent < 8:
+            raise _lib.TagrecError("LightGCN: fused message dropout needs dim_latent in {8,16,...,256}")
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TagrecError("LightGCN: message dropout draws a new seed on the host every step and cannot be captured "
+                                   "in a HIP graph")
+        self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+        return drops + [0.0] * (self.num_layer - len(drops)), (int(self.drop_seed) << 24) + self._drop_calls
 
     def _graph(self):
         return H.node_drop(self.norm_adj, self.node_drop, self.training)
@@ -149,7 +173,8 @@ class LightGCN(TableModel):
     def _propagate(self):
         graph = self._graph()
         if self._fused_ok():
-            return _Propagate.apply(self.table, graph, self.num_layer)
+            drops, seed = self._drops()
+            return _Propagate.apply(self.table, graph, self.num_layer, drops, seed)
         # operator-by-operator path (row folds / message dropout), same order as lightgcn.py:52-60
         x = self.table
         layers = [x]
@@ -166,8 +191,9 @@ class LightGCN(TableModel):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
         nu, ni = self.num_list[0], self.num_list[1]
         if self._fused_ok():
+            drops, seed = self._drops()
             res = _PropagateBprLoss.apply(self.table, self._graph(), self.num_layer, nu, ni, batch_data,
-                                          H.loss_kind_id(self.loss_func), self.reg != 0)
+                                          H.loss_kind_id(self.loss_func), self.reg != 0, drops, seed)
             return res[0], self.reg * res[1]
         all_users, all_items = self.forward()[:2]
         ego = self.embed
