@@ -692,6 +692,7 @@ __global__ void fuse_fold_kernel(const float* __restrict__ part, int n_parts, in
 }
 
 constexpr int kFuseBwdBlocks = 512;
+constexpr int kLightBatch = 4;      // k-steps whose operands the light paths of the weight-gradient kernel load at once
 
 template <int D, int DOUT>
 int launch_fuse_bwd(const float* T0, const float* T1, const float* T2, int64_t n, const float* U, const float* qv,
@@ -720,28 +721,37 @@ int launch_fuse_bwd(const float* T0, const float* T1, const float* T2, int64_t n
 // accumulator tile each), k-group 8 = the 48 vector-level rows (16 per wave), k-group 9 = the small weight
 // gradients G (vector-level filters) and dU (type attention), which are the same kind of node-axis product.  Per-node-group partial sums are
 // folded in group order by fuse_fold_kernel (deterministic).
-template <int D, int DOUT>
-__global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
+template <int D, int DOUT, int NH>
+__global__ __launch_bounds__(kFuseThreads * NH) void tgcn_fuse_wf_kernel(
     const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, const float* __restrict__ bw,
     const float* __restrict__ yvec, const float* __restrict__ wb, const float* __restrict__ outv,
     const float* __restrict__ dOut, const float* __restrict__ dfeat, const float* __restrict__ dS, int64_t n,
-    int64_t rows_per_group, float* __restrict__ part) {
+    int64_t rows_per_group, int main_groups, int64_t rows_per_small_group, float* __restrict__ part_main,
+    float* __restrict__ part_small) {
   constexpr int IB = D / 16, OB = DOUT / 16;
   constexpr int A = 32, AB = A / 16, NF = 6 * kVecC, FB = NF / 16;
-  constexpr int64_t KROWS = static_cast<int64_t>(kBitC) * D + NF;
-  constexpr int64_t PART = KROWS * DOUT + static_cast<int64_t>(NF) * 3 * D + static_cast<int64_t>(D) * A;   // dWf | G | dU
+  constexpr int64_t KBIT = static_cast<int64_t>(kBitC) * D * DOUT;                       // the bit-level rows of dWf
+  constexpr int64_t SMALL = static_cast<int64_t>(NF) * DOUT + static_cast<int64_t>(NF) * 3 * D + static_cast<int64_t>(D) * A;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
-  const int kg = blockIdx.x % 10;
-  const int64_t ng = blockIdx.x / 10;
-  const int64_t lo = ng * rows_per_group;
-  const int64_t hi = (lo + rows_per_group < n) ? lo + rows_per_group : n;
-  float* dst = part + ng * PART;
+  // The first 8 * main_groups blocks are the heavy ones (k-groups 0..7: four bit-level channels each, operands shared
+  // through LDS); the remaining blocks take the two light k-groups (vector-level rows; G and dU) over their own,
+  // finer node groups: those are load-latency bound, so they get more blocks with fewer nodes each.
+  const bool heavy = static_cast<int>(blockIdx.x) < 8 * main_groups;
+  const int rest = static_cast<int>(blockIdx.x) - 8 * main_groups;
+  const int kg = heavy ? blockIdx.x % 8 : 8 + rest % 2;
+  const int64_t ng = heavy ? blockIdx.x / 8 : rest / 2;
+  const int64_t rpg = heavy ? rows_per_group : rows_per_small_group;
+  const int64_t lo = ng * rpg;
+  const int64_t hi = (lo + rpg < n) ? lo + rpg : n;
+  // partial results: heavy blocks [group][KBIT]; light blocks [group][vec rows of dWf | G | dU] (indexed as in [dWf | G | dU])
+  float* dst = heavy ? part_main + ng * KBIT : part_small + ng * SMALL - KBIT;
+  if (!heavy && wave >= 4) return;               // the light paths are written for four waves
   if (kg == 9) {
     // small weight gradients with nodes on the k axis:
     //   G[f][j][d] = sum_nodes dfeat[node][f] e_j[node][d]   (the caller folds G into dw1, dw2, dw3)
     //   dU[d][a]   = sum_nodes sum_j t_j[node][d] dS_j[node][a]
-    float* gdst = dst + KROWS * DOUT;
+    float* gdst = dst + KBIT + static_cast<int64_t>(NF) * DOUT;
     float* udst = gdst + static_cast<int64_t>(NF) * 3 * D;
     const float* Tj[3] = {T0, T1, T2};
     constexpr int IBW = (IB + 3) / 4;              // input-feature blocks per wave: ib = wave + 4 i
@@ -773,22 +783,26 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
         for (int a = 0; a < AB; ++a) rw.ds[j][a] = ok ? dS[node * (3 * A) + j * A + a * 16 + m] : 0.f;
       }
     };
-    RawS cur, nxt;
-    fetch_s(lo, cur);
-    for (int64_t node0 = lo; node0 < hi; node0 += 4) {
-      fetch_s(node0 + 4, nxt);
+    // load-latency bound: the operands of kLightBatch k-steps are fetched together, then multiplied
+    for (int64_t node0 = lo; node0 < hi; node0 += 4 * kLightBatch) {
+      RawS rs[kLightBatch];
 #pragma unroll
-      for (int i = 0; i < IBW; ++i) {
+      for (int u = 0; u < kLightBatch; ++u) fetch_s(node0 + 4 * u, rs[u]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float e = cur.t[j][i] * cur.b[j];
+      for (int u = 0; u < kLightBatch; ++u) {
+        const RawS& cur = rs[u];
 #pragma unroll
-          for (int f = 0; f < FB; ++f) accg[i][f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.df[f], e, accg[i][f][j], 0, 0, 0);
+        for (int i = 0; i < IBW; ++i) {
 #pragma unroll
-          for (int a = 0; a < AB; ++a) accu[i][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.t[j][i], cur.ds[j][a], accu[i][a], 0, 0, 0);
+          for (int j = 0; j < 3; ++j) {
+            const float e = cur.t[j][i] * cur.b[j];
+#pragma unroll
+            for (int f = 0; f < FB; ++f) accg[i][f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.df[f], e, accg[i][f][j], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < AB; ++a) accu[i][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.t[j][i], cur.ds[j][a], accu[i][a], 0, 0, 0);
+          }
         }
       }
-      cur = nxt;
     }
 #pragma unroll
     for (int i = 0; i < IBW; ++i) {
@@ -808,13 +822,109 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
     return;
   }
   if (kg < 8) {
-    const int c = 4 * kg + wave;
+    // NH = 2 (D = Dout = 128): a channel's D x Dout accumulator tile is split over two waves (rows [half IBH, ..)), so a
+    // wave holds 128 accumulator registers instead of 256 and two waves fit a SIMD -- with one, every wait was exposed
+    constexpr int IBH = IB / NH;
+    const int c = 4 * kg + (wave & 3), half = wave >> 2;
     const float c0 = wb[c * 3], c1 = wb[c * 3 + 1], c2 = wb[c * 3 + 2];
-    f32x4 acc[IB][OB];
+    f32x4 acc[IBH][OB];
 #pragma unroll
-    for (int i = 0; i < IB; ++i)
+    for (int i = 0; i < IBH; ++i)
 #pragma unroll
       for (int o = 0; o < OB; ++o) acc[i][o] = zero4();
+    if constexpr ((D == 64 || D == 128) && (DOUT == 64 || DOUT == 128)) {
+      // The four waves (four channels) need the SAME rows of T0, T1, T2, dOut, out and bw; loading them per wave made
+      // 32 waves re-read every node row from L2 (80 GB per call at C4: the kernel sat at 36 % MFMA-busy on that).
+      // They are staged once per block through LDS instead: 8 nodes (two MFMA k-steps) per stage, LDS-DMA, two
+      // buffers.  A row's 16-byte units are rotated by 4 * (node % 4) so that the b32 reads of the four nodes a
+      // k-step touches (lanes q = 0..3) fall on disjoint 16-bank ranges.
+      constexpr int SN = 8;                                   // nodes per stage
+      constexpr int TB = SN * D * 4, GB = SN * DOUT * 4;      // bytes per staged tensor
+      constexpr int STAGE = 3 * TB + 2 * GB + 128;            // T0 T1 T2 | dOut | out | bw (8 x 3 floats, padded)
+      // Node rows come from HBM the first time (eight blocks share a node range, the other seven hit L2): a stage is
+      // two k-steps of MFMAs, far shorter than that miss, so THREE stages are kept in flight (four buffers) and the
+      // waits are counted -- `s_waitcnt vmcnt(k * CNT)` + a raw s_barrier, never the vmcnt(0) of __syncthreads().
+      constexpr int AHEAD = 3, NBUF = AHEAD + 1;
+      __shared__ __attribute__((aligned(1024))) char sbuf[NBUF][STAGE];
+      const float* srcT[3] = {T0, T1, T2};
+      constexpr int WPB = 4 * NH;
+      constexpr int PT = TB / 1024, PG = GB / 1024;           // 1 KiB pieces per tensor
+      constexpr int NPIECE = 3 * PT + 2 * PG + 1;             // + the bw piece
+      constexpr int CNT = (NPIECE + WPB - 1) / WPB;           // DMA instructions per wave and stage (uniform: see below)
+      auto issue = [&](int64_t node0, int buf) {
+        // piece ids: [0, 3 PT) rows of T0..T2, then PG of dOut, PG of out, last = bw.  Wave w takes ids w, w + WPB, ..;
+        // a wave whose last slot has no piece repeats its previous one, so that every wave issues exactly CNT.
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+          int id = wave + j * WPB;
+          if (id >= NPIECE) id -= WPB;
+          if (id == NPIECE - 1) {                               // bw: 24 consecutive floats of [n, 3]
+            int64_t e = node0 * 3 + (lane < 3 * SN ? lane : 0);
+            if (e >= n * 3) e = n * 3 - 1;
+            if (lane < 3 * SN)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bw + e),
+                                               (__attribute__((address_space(3))) void*)&sbuf[buf][3 * TB + 2 * GB], 4, 0, 0);
+            continue;
+          }
+          const bool is_t = id < 3 * PT;
+          const int gi = is_t ? 0 : (id - 3 * PT) / PG;                                  // 0: dOut, 1: out
+          const float* base = is_t ? srcT[id / PT] : (gi == 0 ? dOut : outv);
+          const int W = is_t ? D : DOUT;
+          const int piece = is_t ? id % PT : (id - 3 * PT) % PG;
+          const int off_bytes = is_t ? (id / PT) * TB : 3 * TB + gi * GB;
+          const int lanes_per_row = W / 4, rpp = 256 / W;
+          const int nd = piece * rpp + lane / lanes_per_row;          // node slot 0..7 inside the stage
+          const int upos = lane % lanes_per_row;                       // unit position inside the LDS row
+          const int u = (upos - 4 * (nd & 3)) & (lanes_per_row - 1);   // source unit: rows are stored rotated
+          int64_t node = node0 + nd;
+          if (node >= n) node = n - 1;                                 // clamped; masked out when read
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + node * W + u * 4),
+                                           (__attribute__((address_space(3))) void*)&sbuf[buf][off_bytes + piece * 1024], 16, 0, 0);
+        }
+      };
+      const int64_t n_stage = (hi - lo + SN - 1) / SN;
+      for (int k = 0; k < AHEAD; ++k)
+        if (k < n_stage) issue(lo + k * SN, k);
+      for (int64_t st = 0; st < n_stage; ++st) {
+        const int64_t after = n_stage - 1 - st < AHEAD - 1 ? n_stage - 1 - st : AHEAD - 1;   // stages in flight beyond st
+        if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CNT) : "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // stage st is in LDS for everyone; buffer (st-1) % NBUF is free
+        asm volatile("" ::: "memory");
+        if (st + AHEAD < n_stage) issue(lo + (st + AHEAD) * SN, static_cast<int>((st + AHEAD) % NBUF));
+        const char* sb = sbuf[st % NBUF];
+#pragma unroll
+        for (int ks = 0; ks < SN / 4; ++ks) {
+          const int nd = ks * 4 + q;                                   // node slot of this lane's k index
+          const bool ok = lo + st * SN + nd < hi;
+          const float* bwp = reinterpret_cast<const float*>(sb + 3 * TB + 2 * GB) + nd * 3;
+          const float b0 = bwp[0], b1 = bwp[1], b2 = bwp[2];
+          float y[IBH], g[OB];
+#pragma unroll
+          for (int i = 0; i < IBH; ++i) {
+            const int w = nd * D + 4 * ((4 * (half * IBH + i) + (m >> 2) + 4 * q) & (D / 4 - 1)) + (m & 3);
+            const float e0 = reinterpret_cast<const float*>(sb)[w] * b0;
+            const float e1 = reinterpret_cast<const float*>(sb + TB)[w] * b1;
+            const float e2 = reinterpret_cast<const float*>(sb + 2 * TB)[w] * b2;
+            // same operation order as the forward kernel, so the ReLU mask is the forward's
+            y[i] = fmaxf(fmaf(c0, e0, fmaf(c1, e1, c2 * e2)), 0.f);
+          }
+#pragma unroll
+          for (int o = 0; o < OB; ++o) {
+            const int w = nd * DOUT + 4 * ((4 * o + (m >> 2) + 4 * q) & (DOUT / 4 - 1)) + (m & 3);
+            const float go = reinterpret_cast<const float*>(sb + 3 * TB)[w];
+            const float ov = reinterpret_cast<const float*>(sb + 3 * TB + GB)[w];
+            g[o] = (ok && ov > 0.f) ? go : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < IBH; ++i)
+#pragma unroll
+            for (int o = 0; o < OB; ++o) acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[i], g[o], acc[i][o], 0, 0, 0);
+        }
+      }
+    } else {
+      static_assert(NH == 1 || ((D == 64 || D == 128) && (DOUT == 64 || DOUT == 128)), "row halves only with staged operands");
     // software pipeline: the raw operands of step s+1 are in flight while step s runs its IB x OB MFMAs
     // (one wave per SIMD here -- the accumulator tile fills the register file -- so nothing else hides the latency)
     struct Raw { float t0[IB], t1[IB], t2[IB], go[OB], ov[OB], b0, b1, b2; };
@@ -852,27 +962,38 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
         for (int o = 0; o < OB; ++o) acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[i], g[o], acc[i][o], 0, 0, 0);
       cur = nxt;
     }
+    }
 #pragma unroll
-    for (int i = 0; i < IB; ++i)
+    for (int i = 0; i < IBH; ++i)
 #pragma unroll
       for (int o = 0; o < OB; ++o)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          dst[(static_cast<int64_t>(c) * D + i * 16 + q * 4 + v) * DOUT + o * 16 + m] = acc[i][o][v];
+          dst[(static_cast<int64_t>(c) * D + (half * IBH + i) * 16 + q * 4 + v) * DOUT + o * 16 + m] = acc[i][o][v];
   } else if (wave < 3) {
     f32x4 acc[OB];
 #pragma unroll
     for (int o = 0; o < OB; ++o) acc[o] = zero4();
-    for (int64_t node0 = lo; node0 < hi; node0 += 4) {
-      const int64_t node = node0 + q;
-      const bool ok = node < hi;
-      const float y = ok ? yvec[node * (6 * kVecC) + wave * 16 + m] : 0.f;
+    // load-latency bound (16 MFMAs per 4 nodes): the operands of kLightBatch k-steps are fetched together
+    for (int64_t node0 = lo; node0 < hi; node0 += 4 * kLightBatch) {
+      float y[kLightBatch], go[kLightBatch][OB], ov[kLightBatch][OB];
 #pragma unroll
-      for (int o = 0; o < OB; ++o) {
-        const int64_t off = node * DOUT + o * 16 + m;
-        const float g = (ok && outv[off] > 0.f) ? dOut[off] : 0.f;
-        acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(y, g, acc[o], 0, 0, 0);
+      for (int u = 0; u < kLightBatch; ++u) {
+        const int64_t node = node0 + 4 * u + q;
+        const bool ok = node < hi;
+        y[u] = ok ? yvec[node * (6 * kVecC) + wave * 16 + m] : 0.f;
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+          const int64_t off = node * DOUT + o * 16 + m;
+          go[u][o] = ok ? dOut[off] : 0.f;
+          ov[u][o] = ok ? outv[off] : 0.f;
+        }
       }
+#pragma unroll
+      for (int u = 0; u < kLightBatch; ++u)
+#pragma unroll
+        for (int o = 0; o < OB; ++o)
+          acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[u], ov[u][o] > 0.f ? go[u][o] : 0.f, acc[o], 0, 0, 0);
     }
 #pragma unroll
     for (int o = 0; o < OB; ++o)
@@ -882,26 +1003,34 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_wf_kernel(
   }
 }
 
-constexpr int kWfGroups = 25;        // 10 x 25 = 250 blocks: one 4-wave block per CU
+constexpr int kWfGroups = 23;        // 8 x 23 heavy blocks + 2 x 36 light ones = 256: one block per CU; the split
+constexpr int kWfSmallGroups = 36;   // equalises their measured times (heavy-only 13.4 ms at 26 groups, light-only 11.3 ms at 48; 1 M nodes, D = 128)
 
 template <int D, int DOUT>
 int launch_fuse_wf(const float* T0, const float* T1, const float* T2, const float* bw, const float* yvec, const float* wb,
                    const float* outv, const float* dOut, const float* dfeat, const float* dS, int64_t n, float* dWf,
                    float* ws, hipStream_t s) {
-  int64_t groups = (n + 255) / 256;
-  if (groups > kWfGroups) groups = kWfGroups;
-  if (groups < 1) groups = 1;
-  int64_t per = (n + groups - 1) / groups;
-  per = (per + 3) / 4 * 4;
-  groups = (n + per - 1) / per;
-  tgcn_fuse_wf_kernel<D, DOUT><<<static_cast<unsigned>(10 * groups), kFuseThreads, 0, s>>>(T0, T1, T2, bw, yvec, wb, outv, dOut,
-                                                                                           dfeat, dS, n, per, ws);
+  constexpr int64_t KBIT = static_cast<int64_t>(kBitC) * D * DOUT;
+  constexpr int64_t SMALL = static_cast<int64_t>(6 * kVecC) * DOUT + static_cast<int64_t>(6 * kVecC) * 3 * D + static_cast<int64_t>(D) * 32;
+  auto split = [&](int64_t want, int64_t* per) {
+    int64_t groups = (n + 255) / 256;
+    if (groups > want) groups = want;
+    if (groups < 1) groups = 1;
+    *per = ((n + groups - 1) / groups + 7) / 8 * 8;
+    return (n + *per - 1) / *per;
+  };
+  int64_t per = 0, per_small = 0;
+  const int64_t groups = split(kWfGroups, &per), small_groups = split(kWfSmallGroups, &per_small);
+  float* ws_small = ws + static_cast<int64_t>(kWfGroups) * KBIT;
+  constexpr int NH = (D == 128 && DOUT == 128) ? 2 : 1;
+  tgcn_fuse_wf_kernel<D, DOUT, NH><<<static_cast<unsigned>(8 * groups + 2 * small_groups), kFuseThreads * NH, 0, s>>>(
+      T0, T1, T2, bw, yvec, wb, outv, dOut, dfeat, dS, n, per, static_cast<int>(groups), per_small, ws, ws_small);
   TAGREC_LAUNCH_CHECK();
-  // one contiguous result [dWf | G | dU] (the caller hands a buffer of that size)
-  const int64_t elems = (static_cast<int64_t>(kBitC) * D + 6 * kVecC) * DOUT + static_cast<int64_t>(6 * kVecC) * 3 * D +
-                        static_cast<int64_t>(D) * 32;
-  fuse_fold_kernel<<<static_cast<unsigned>((elems + 255) / 256), 256, 0, s>>>(ws, static_cast<int>(groups),
-                                                                            static_cast<int>(elems), dWf);
+  // one contiguous result [dWf | G | dU] (the caller hands a buffer of that size): bit-level rows, then the rest
+  fuse_fold_kernel<<<static_cast<unsigned>((KBIT + 255) / 256), 256, 0, s>>>(ws, static_cast<int>(groups), static_cast<int>(KBIT), dWf);
+  TAGREC_LAUNCH_CHECK();
+  fuse_fold_kernel<<<static_cast<unsigned>((SMALL + 255) / 256), 256, 0, s>>>(ws_small, static_cast<int>(small_groups),
+                                                                            static_cast<int>(SMALL), dWf + KBIT);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
@@ -973,7 +1102,8 @@ extern "C" int64_t tagrec_tgcn_fuse_wf_result(int D, int Dout) {      // floats 
 }
 
 extern "C" int64_t tagrec_tgcn_fuse_wf_workspace(int D, int Dout) {
-  return static_cast<int64_t>(kWfGroups) * tagrec_tgcn_fuse_wf_result(D, Dout);
+  const int64_t kbit = static_cast<int64_t>(kBitC) * D * Dout;
+  return static_cast<int64_t>(kWfGroups) * kbit + static_cast<int64_t>(kWfSmallGroups) * (tagrec_tgcn_fuse_wf_result(D, Dout) - kbit);
 }
 
 extern "C" int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, const float* bw,
