@@ -92,6 +92,26 @@ int tagrec_spmm_normbwd_drop_f32(const tagrec_graph* g, const float* G_in, const
                                  uint64_t seed, float* G_out, int D, void* stream);
 int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream);
 
+/* Backward layers on a ROW-SPARSE gradient.  The gradient that enters the backward chain is non-zero on the <= 3 B rows
+ * of the batch only, and one hop later on their neighbours, so most rows a backward product would gather are zero.
+ * row_flags[c] (uint8) != 0 iff row c holds a non-zero; *count (uint32, device) = how many rows are flagged.  A product
+ * given in_flags / in_count does not fetch rows flagged zero -- the result is bit-identical, a x 0 adds exactly 0 -- and
+ * consults the flags only while they cover less than half of the rows (decided on the device, no host read).
+ *   rownorm_bwd_flags   : tagrec_rownorm_bwd_f32 + flags / count of its output rows (the head of the chain)
+ *   spmm_normbwd_sparse : tagrec_spmm_normbwd_drop_f32 reading in_flags (may be NULL) and writing out_flags / out_count
+ *                         (may be NULL)
+ *   spmm_axpy_sparse    : tagrec_spmm_axpy_f32 reading in_flags */
+int tagrec_rownorm_bwd_flags_f32(const float* X_raw, const float* inv_norm, const float* dZ, int64_t lddz,
+                                 float d_scale, float* dX, int accumulate, int64_t n_rows, int D,
+                                 uint8_t* row_flags, unsigned* count, void* stream);
+int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                   const unsigned* in_count, const float* X_raw, const float* inv_norm,
+                                   const float* dZ, float d_scale, float drop_p, uint64_t seed, float* G_out,
+                                   uint8_t* out_flags, unsigned* out_count, int D, void* stream);
+int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                const unsigned* in_count, const float* B, float b_scale, float* G_out, int D,
+                                void* stream);
+
 /* ---- column-sharded tables (feature sharding over GPUs: every rank holds D/G columns of every row) ---------------
  * Whatever reduces over a row's columns is split into a local part, an all-reduce done by the caller, and an apply:
  *   spmm_ss          : Y = A @ X;  ss[r] = sum_c Y[r,c]^2 over the local columns

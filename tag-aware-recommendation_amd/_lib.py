@@ -82,6 +82,11 @@ _SIGNATURES = {
     "tagrec_spmm_normbwd_drop_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, ctypes.c_uint64, c_void_p,
                                      c_int, c_void_p],
     "tagrec_dropout_f32": [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p],
+    "tagrec_rownorm_bwd_flags_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int, c_int64, c_int, c_void_p,
+                                     c_void_p, c_void_p],
+    "tagrec_spmm_normbwd_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                       ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_spmm_axpy_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p],
     "tagrec_eval_topk_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                              c_void_p, c_void_p],
     "tagrec_sample_negative_i64": [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, ctypes.c_uint64, c_void_p, c_void_p],

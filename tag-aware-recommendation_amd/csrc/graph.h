@@ -43,4 +43,7 @@ struct LongView {
 // Grow g->slab to n_chunks x width floats.
 int ensure_slab(const tagrec_graph* g, int width);
 
+// *count = number of non-zero bytes of flags[0..n) (rowops.hip)
+int count_flags(const uint8_t* flags, int64_t n, unsigned* count, hipStream_t s);
+
 }  // namespace tagrec

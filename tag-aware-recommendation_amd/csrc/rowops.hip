@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kThreads) void rownorm_bwd_kernel(const float* __re
                                                                const float* __restrict__ inv_norm,
                                                                const float* __restrict__ dZ, int64_t lddz, float s,
                                                                float* __restrict__ dX, int accumulate,
-                                                               int64_t n_rows, int D) {
+                                                               int64_t n_rows, int D, uint8_t* __restrict__ row_flags) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t r = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
   if (r >= n_rows) return;
@@ -53,10 +53,27 @@ __global__ __launch_bounds__(kThreads) void rownorm_bwd_kernel(const float* __re
   dot = wave_sum(dot);
   if (inv >= 1e12f) dot = 0.f;  // norm was clamped to eps: the denominator is a constant
   float* o = dX + r * D;
+  bool nz = false;
   for (int k = lane; k < D; k += kWave) {
-    const float g = inv * (dz[k] * s - x[k] * inv * dot);
-    o[k] = accumulate ? o[k] + g : g;
+    float g = inv * (dz[k] * s - x[k] * inv * dot);
+    if (accumulate) g += o[k];
+    o[k] = g;
+    nz |= g != 0.f;
   }
+  if (row_flags) {                        // 1 iff the row holds a non-zero (see EpiArgs::in_flags in spmm.hip)
+    const bool any = __any(nz);
+    if (lane == 0) row_flags[r] = any;
+  }
+}
+
+// number of non-zero entries of a byte array (the row flags above), added to *count
+__global__ __launch_bounds__(kThreads) void count_flags_kernel(const uint8_t* __restrict__ flags, int64_t n, unsigned* __restrict__ count) {
+  unsigned c = 0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) c += flags[i] != 0;
+#pragma unroll
+  for (int m = 1; m < kWave; m <<= 1) c += __shfl_xor(c, m);
+  if ((threadIdx.x & (kWave - 1)) == 0 && c) atomicAdd(count, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,9 +429,35 @@ extern "C" int tagrec_rownorm_bwd_f32(const float* X_raw, const float* inv_norm,
   if (n_rows == 0) return TAGREC_OK;
   const unsigned blocks = static_cast<unsigned>((n_rows + 3) / 4);
   rownorm_bwd_kernel<<<blocks, kThreads, 0, static_cast<hipStream_t>(stream)>>>(X_raw, inv_norm, dZ, lddz, d_scale, dX,
-                                                                                accumulate, n_rows, D);
+                                                                                accumulate, n_rows, D, nullptr);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
+}
+
+namespace tagrec {
+int count_flags(const uint8_t* flags, int64_t n, unsigned* count, hipStream_t s) {
+  TAGREC_HIP(hipMemsetAsync(count, 0, sizeof(unsigned), s));
+  if (n == 0) return TAGREC_OK;
+  int64_t blocks = (n + kThreads * 16 - 1) / (kThreads * 16);
+  if (blocks > 256) blocks = 256;
+  count_flags_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, s>>>(flags, n, count);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+}  // namespace tagrec
+
+extern "C" int tagrec_rownorm_bwd_flags_f32(const float* X_raw, const float* inv_norm, const float* dZ, int64_t lddz,
+                                            float d_scale, float* dX, int accumulate, int64_t n_rows, int D,
+                                            uint8_t* row_flags, unsigned* count, void* stream) {
+  TAGREC_REQUIRE(X_raw && inv_norm && dZ && dX && row_flags && count, "rownorm_bwd_flags: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && D >= 1 && lddz >= D, "rownorm_bwd_flags: bad shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_rows > 0) {
+    rownorm_bwd_kernel<<<static_cast<unsigned>((n_rows + 3) / 4), kThreads, 0, s>>>(X_raw, inv_norm, dZ, lddz, d_scale, dX,
+                                                                                   accumulate, n_rows, D, row_flags);
+    TAGREC_LAUNCH_CHECK();
+  }
+  return count_flags(row_flags, n_rows, count, s);
 }
 
 extern "C" int tagrec_bpr_fwd_f32(const float* U, const float* I, int64_t ld, int D, const float* Ureg,

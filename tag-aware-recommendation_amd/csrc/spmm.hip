@@ -38,6 +38,13 @@ struct EpiArgs {
   float s;
   DropMask drop;          // NORM_ACC: message dropout of the product before it is stored / normalised (lightgcn.py:56);
                           // NORMBWD: the same mask on the gradient leaving this layer.  p = 0: off
+  // Row-sparse operand (the gradient at the start of the backward chain is non-zero on the <= 3 B batch rows only, and
+  // one hop later on their neighbours): in_flags[c] != 0 iff row c of the gathered matrix has a non-zero; rows flagged
+  // zero are not fetched (a x 0 adds exactly 0, so the result is unchanged).  *in_count = number of flagged rows; the
+  // flags are consulted only while they cover less than half of the rows.  out_flags: the same for this product's output.
+  const uint8_t* in_flags;
+  const unsigned* in_count;
+  uint8_t* out_flags;
 };
 
 // Streamed-once data (indices, values, epilogue operands, outputs) is moved with non-temporal accesses so it does
@@ -66,9 +73,9 @@ __device__ __forceinline__ float f4_dot(const float4& a, const float4& b) {
 
 // Sum of val[j] * X[col[j], :] over j in [start, end).  LPR = lanes per row = D/4.  On return every
 // lane holds the full sum for its float4 column (lane % LPR).
-template <int LPR>
+template <int LPR, bool FLAGS = false>
 __device__ __forceinline__ float4 gather_rows(const GraphView& g, const float* __restrict__ X,
-                                              int64_t start, int64_t end, int lane) {
+                                              int64_t start, int64_t end, int lane, const uint8_t* __restrict__ flags = nullptr) {
   constexpr int NPI = kWave / LPR;  // neighbour rows per wave-instruction
   const int q = lane / LPR;
   const float4* __restrict__ Xv = reinterpret_cast<const float4*>(X) + (lane % LPR);
@@ -80,6 +87,7 @@ __device__ __forceinline__ float4 gather_rows(const GraphView& g, const float* _
     if (lane < n) {
       my_col = ld_stream(g.col + base + lane);
       my_val = ld_stream(g.val + base + lane);
+      if constexpr (FLAGS) my_val = flags[my_col] ? my_val : 0.f;      // a zero weight marks "row not needed"
     }
     const int groups = (n + NPI - 1) / NPI;
     for (int gi = 0; gi < groups; gi += 4) {
@@ -90,7 +98,7 @@ __device__ __forceinline__ float4 gather_rows(const GraphView& g, const float* _
         const int j = (gi + u) * NPI + q;
         const int c = __shfl(my_col, j & (kWave - 1));
         const float w = __shfl(my_val, j & (kWave - 1));
-        const bool ok = j < n;
+        const bool ok = FLAGS ? (j < n && w != 0.f) : (j < n);
         v[u] = ok ? w : 0.f;
         x[u] = ok ? Xv[static_cast<int64_t>(c) * LPR] : f4_zero();
       }
@@ -153,6 +161,10 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
     float4 o = make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w);
     drop4(e.drop, off, o.x, o.y, o.z, o.w);
     if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, o);
+    if (e.out_flags) {
+      const float nz = group_sum<LPR>((o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) ? 1.f : 0.f);
+      if (lane == 0) e.out_flags[r] = nz != 0.f;
+    }
   } else if constexpr (EPI == EPI_AXPY) {
     const float4 b = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
     if (writer)
@@ -190,7 +202,8 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
     const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
-    const float4 acc = gather_rows<LPR>(g, X, start, end, lane);
+    const bool sparse = e.in_flags && 2ull * (*e.in_count) < static_cast<unsigned long long>(g.n_rows);
+    const float4 acc = sparse ? gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags) : gather_rows<LPR>(g, X, start, end, lane);
     if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[c * LPR + lane] = acc;
     return;
   }
@@ -198,7 +211,8 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
   if (r >= g.n_rows) return;
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
   if (end - start > kLongRow) return;  // chunked above, folded by spmm_finish_kernel
-  const float4 acc = gather_rows<LPR>(g, X, start, end, lane);
+  const bool sparse = e.in_flags && 2ull * (*e.in_count) < static_cast<unsigned long long>(g.n_rows);
+  const float4 acc = sparse ? gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags) : gather_rows<LPR>(g, X, start, end, lane);
   row_epilogue<LPR, EPI>(acc, r, lane, e);
 }
 
@@ -487,14 +501,14 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
 }  // namespace
 
 extern "C" int tagrec_spmm_f32(const tagrec_graph* g, const float* X, float* Y, int D, void* stream) {
-  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}};
+  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NONE>(g, X, e, D, stream, "spmm");
 }
 
 extern "C" int tagrec_spmm_norm_acc_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
                                         float* acc, float acc_scale, int D, void* stream) {
   TAGREC_REQUIRE(inv_norm != nullptr && acc != nullptr, "spmm_norm_acc: null inv_norm or acc");
-  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{0.f, 0}};
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc");
 }
 
@@ -502,20 +516,20 @@ extern "C" int tagrec_spmm_normbwd_f32(const tagrec_graph* g, const float* G_in,
                                        const float* inv_norm, const float* dZ, float d_scale, float* G_out,
                                        int D, void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr, "spmm_normbwd: null X_raw, inv_norm or dZ");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{0.f, 0}};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd");
 }
 
 extern "C" int tagrec_spmm_axpy_f32(const tagrec_graph* g, const float* G_in, const float* B, float b_scale,
                                     float* G_out, int D, void* stream) {
   TAGREC_REQUIRE(B != nullptr, "spmm_axpy: null B");
-  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}};
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy");
 }
 
 extern "C" int tagrec_spmm_ss_f32(const tagrec_graph* g, const float* X, float* Y, float* ss, int D, void* stream) {
   TAGREC_REQUIRE(ss != nullptr, "spmm_ss: null ss");
-  EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}};
+  EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_SS>(g, X, e, D, stream, "spmm_ss");
 }
 
@@ -524,7 +538,7 @@ extern "C" int tagrec_spmm_normbwd_dot_f32(const tagrec_graph* g, const float* G
                                            float* G_out, int D, void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr && dot != nullptr,
                  "spmm_normbwd_dot: null X_raw, inv_norm, dZ or dot");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORMBWD_DOT>(g, G_in, e, D, stream, "spmm_normbwd_dot");
 }
 
@@ -534,7 +548,7 @@ extern "C" int tagrec_spmm_norm_acc_drop_f32(const tagrec_graph* g, const float*
   TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_norm_acc_drop: p must be in [0, 1)");
   TAGREC_REQUIRE(drop_p == 0.f || (D % 4 == 0 && D <= 256 && (D & (D - 1)) == 0 && D >= 8),
                  "spmm_norm_acc_drop: dropout needs a vector-kernel width (8..256, power of two)");
-  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}};
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc_drop");
 }
 
@@ -545,6 +559,31 @@ extern "C" int tagrec_spmm_normbwd_drop_f32(const tagrec_graph* g, const float* 
   TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_normbwd_drop: p must be in [0, 1)");
   TAGREC_REQUIRE(drop_p == 0.f || (D % 4 == 0 && D <= 256 && (D & (D - 1)) == 0 && D >= 8),
                  "spmm_normbwd_drop: dropout needs a vector-kernel width (8..256, power of two)");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd_drop");
+}
+
+// ---- backward layers on a row-sparse gradient (see EpiArgs::in_flags) -----------------------------------------------
+extern "C" int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                              const unsigned* in_count, const float* X_raw, const float* inv_norm,
+                                              const float* dZ, float d_scale, float drop_p, uint64_t seed, float* G_out,
+                                              uint8_t* out_flags, unsigned* out_count, int D, void* stream) {
+  TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr, "spmm_normbwd_sparse: null X_raw, inv_norm or dZ");
+  TAGREC_REQUIRE((in_flags == nullptr) == (in_count == nullptr), "spmm_normbwd_sparse: in_flags and in_count go together");
+  TAGREC_REQUIRE((out_flags == nullptr) == (out_count == nullptr), "spmm_normbwd_sparse: out_flags and out_count go together");
+  TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_normbwd_sparse: p must be in [0, 1)");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_normbwd_sparse: D must be 8 .. 256, a power of two");
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}, in_flags, in_count, out_flags};
+  int rc = launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd_sparse");
+  if (rc != TAGREC_OK || !out_flags) return rc;
+  return count_flags(out_flags, g->n_rows, out_count, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                           const unsigned* in_count, const float* B, float b_scale, float* G_out, int D,
+                                           void* stream) {
+  TAGREC_REQUIRE(B != nullptr && in_flags != nullptr && in_count != nullptr, "spmm_axpy_sparse: null B, in_flags or in_count");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_sparse: D must be 8 .. 256, a power of two");
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr};
+  return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_sparse");
 }

@@ -274,6 +274,20 @@ class Graph:
         self._call("spmm_normbwd", _lib.load().tagrec_spmm_normbwd_f32, self._h, _lib.ptr(g_in), _lib.ptr(x_raw),
                    _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), _lib.ptr(g_out), D, _lib.stream_ptr())
 
+    def spmm_normbwd_sparse(self, g_in, in_flags, in_count, x_raw, inv_norm, dz, d_scale, g_out, out_flags, out_count,
+                            drop_p=0.0, seed=0):
+        """`spmm_normbwd` on a row-sparse g_in: rows whose in_flags byte is 0 are not gathered (same result); writes the
+        flags / count of its own output when out_flags is given."""
+        D = self._chk_x(g_in, self.shape[1], "spmm_normbwd g_in")
+        self._call("spmm_normbwd", _lib.load().tagrec_spmm_normbwd_sparse_f32, self._h, _lib.ptr(g_in), _lib.ptr(in_flags),
+                   _lib.ptr(in_count), _lib.ptr(x_raw), _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), float(drop_p),
+                   int(seed), _lib.ptr(g_out), _lib.ptr(out_flags), _lib.ptr(out_count), D, _lib.stream_ptr())
+
+    def spmm_axpy_sparse(self, g_in, in_flags, in_count, b, b_scale, g_out):
+        D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")
+        self._call("spmm_axpy", _lib.load().tagrec_spmm_axpy_sparse_f32, self._h, _lib.ptr(g_in), _lib.ptr(in_flags),
+                   _lib.ptr(in_count), _lib.ptr(b), float(b_scale), _lib.ptr(g_out), D, _lib.stream_ptr())
+
     def spmm_axpy(self, g_in, b, b_scale, g_out):
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")
         for t, nm in ((b, "b"), (g_out, "g_out")):

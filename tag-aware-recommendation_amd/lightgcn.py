@@ -55,16 +55,36 @@ def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0):
     n, D = d_out.shape
     lib = _lib.load()
     g = torch.empty_like(d_out)
-    _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(raws[L - 1]), _lib.ptr(invs[L - 1]), _lib.ptr(d_out), D, s,
-                                          _lib.ptr(g), 0, n, D, _lib.stream_ptr()), "rownorm_bwd")
+    # The gradient is non-zero on the batch rows only at the head of the chain and spreads by one hop per layer:
+    # every product is told which rows of its operand hold a non-zero and leaves the others unfetched (bit-identical
+    # result; the kernel ignores the flags once they cover half of the rows, without a host round trip).
+    sparse = D in (8, 16, 32, 64, 128, 256)
+    if sparse:
+        flags = [torch.empty(n, dtype=torch.uint8, device=d_out.device) for _ in range(2)]
+        counts = torch.zeros(2, dtype=torch.int32, device=d_out.device)
+        _lib.check(lib.tagrec_rownorm_bwd_flags_f32(_lib.ptr(raws[L - 1]), _lib.ptr(invs[L - 1]), _lib.ptr(d_out), D, s,
+                                                    _lib.ptr(g), 0, n, D, _lib.ptr(flags[0]), _lib.ptr(counts[0:1]),
+                                                    _lib.stream_ptr()), "rownorm_bwd_flags")
+    else:
+        _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(raws[L - 1]), _lib.ptr(invs[L - 1]), _lib.ptr(d_out), D, s,
+                                              _lib.ptr(g), 0, n, D, _lib.stream_ptr()), "rownorm_bwd")
     if drops and drops[L - 1] > 0:
-        H.message_drop(g, drops[L - 1], _layer_seed(seed, L - 1), out=g)
+        H.message_drop(g, drops[L - 1], _layer_seed(seed, L - 1), out=g)     # flags stay a superset of the non-zero rows
+    cur = 0
     for k in range(L - 2, -1, -1):
         gn = torch.empty_like(d_out)
-        graph_t.spmm_normbwd(g, raws[k], invs[k], d_out, s, gn, drops[k] if drops else 0.0, _layer_seed(seed, k))
+        if sparse:
+            graph_t.spmm_normbwd_sparse(g, flags[cur], counts[cur:cur + 1], raws[k], invs[k], d_out, s, gn, flags[1 - cur],
+                                        counts[1 - cur:2 - cur], drops[k] if drops else 0.0, _layer_seed(seed, k))
+            cur = 1 - cur
+        else:
+            graph_t.spmm_normbwd(g, raws[k], invs[k], d_out, s, gn, drops[k] if drops else 0.0, _layer_seed(seed, k))
         g = gn
     g0 = torch.empty_like(d_out)
-    graph_t.spmm_axpy(g, d_out, s, g0)
+    if sparse:
+        graph_t.spmm_axpy_sparse(g, flags[cur], counts[cur:cur + 1], d_out, s, g0)
+    else:
+        graph_t.spmm_axpy(g, d_out, s, g0)
     return g0
 
 
