@@ -96,7 +96,7 @@ int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t 
  * of the batch only, and one hop later on their neighbours, so most rows a backward product would gather are zero.
  * row_flags[c] (uint8) != 0 iff row c holds a non-zero; *count (uint32, device) = how many rows are flagged.  A product
  * given in_flags / in_count does not fetch rows flagged zero -- the result is bit-identical, a x 0 adds exactly 0 -- and
- * consults the flags only while they cover less than half of the rows (decided on the device, no host read).
+ * consults the flags only while they cover less than 4/5 of the rows (decided on the device, no host read).
  *   rownorm_bwd_flags   : tagrec_rownorm_bwd_f32 + flags / count of its output rows (the head of the chain)
  *   spmm_normbwd_sparse : tagrec_spmm_normbwd_drop_f32 reading in_flags (may be NULL) and writing out_flags / out_count
  *                         (may be NULL)

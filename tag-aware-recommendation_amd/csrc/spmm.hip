@@ -41,7 +41,8 @@ struct EpiArgs {
   // Row-sparse operand (the gradient at the start of the backward chain is non-zero on the <= 3 B batch rows only, and
   // one hop later on their neighbours): in_flags[c] != 0 iff row c of the gathered matrix has a non-zero; rows flagged
   // zero are not fetched (a x 0 adds exactly 0, so the result is unchanged).  *in_count = number of flagged rows; the
-  // flags are consulted only while they cover less than half of the rows.  out_flags: the same for this product's output.
+  // flags are consulted only while they cover less than 4/5 of the rows (each check is an extra L2 read per stored entry).
+  // out_flags: the same for this product's output.
   const uint8_t* in_flags;
   const unsigned* in_count;
   uint8_t* out_flags;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
     const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
-    const bool sparse = e.in_flags && 2ull * (*e.in_count) < static_cast<unsigned long long>(g.n_rows);
+    const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_rows);
     const float4 acc = sparse ? gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags) : gather_rows<LPR>(g, X, start, end, lane);
     if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[c * LPR + lane] = acc;
     return;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
   if (r >= g.n_rows) return;
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
   if (end - start > kLongRow) return;  // chunked above, folded by spmm_finish_kernel
-  const bool sparse = e.in_flags && 2ull * (*e.in_count) < static_cast<unsigned long long>(g.n_rows);
+  const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_rows);
   const float4 acc = sparse ? gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags) : gather_rows<LPR>(g, X, start, end, lane);
   row_epilogue<LPR, EPI>(acc, r, lane, e);
 }

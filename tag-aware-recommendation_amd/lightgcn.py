@@ -57,7 +57,7 @@ def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0):
     g = torch.empty_like(d_out)
     # The gradient is non-zero on the batch rows only at the head of the chain and spreads by one hop per layer:
     # every product is told which rows of its operand hold a non-zero and leaves the others unfetched (bit-identical
-    # result; the kernel ignores the flags once they cover half of the rows, without a host round trip).
+    # result; the kernel ignores the flags once they cover 4/5 of the rows, without a host round trip).
     sparse = D in (8, 16, 32, 64, 128, 256)
     if sparse:
         flags = [torch.empty(n, dtype=torch.uint8, device=d_out.device) for _ in range(2)]
