@@ -171,11 +171,33 @@ class _FusedDense(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         t0, t1, t2, U, q, p, wb, w1, w2, w3, Wf, bf, out, bw = ctx.saved_tensors
+        n = t0.shape[0]
+        d_out = d_out.contiguous()
+        # The block is row-local: row r of every input gradient, and row r's share of every weight gradient, is a
+        # multiple of d_out[r].  The gradient of a BPR batch reaches only the batch rows in the last layer and their
+        # sampled neighbours one layer down, so the rows with d_out[r] == 0 are dropped before the kernels run (exact:
+        # they contribute 0) and the results scattered back.  One host read of the row count per call.
+        active = None
+        if n >= _SPARSE_MIN_ROWS:
+            nz = torch.nonzero(d_out.abs().amax(dim=1) > 0).flatten()
+            if nz.numel() * 2 < n:
+                active = nz
+        if active is None:
+            return _FusedDense._backward_rows(t0, t1, t2, U, q, p, wb, w1, w2, w3, Wf, out, bw, d_out)
+        if active.numel() == 0:
+            z = torch.zeros_like
+            return (z(t0), z(t1), z(t2), z(U), z(q), z(p), z(wb), z(w1), z(w2), z(w3), z(Wf), torch.zeros_like(bf), None)
+        sel = lambda x: x.index_select(0, active)
+        res = _FusedDense._backward_rows(sel(t0), sel(t1), sel(t2), U, q, p, wb, w1, w2, w3, Wf, sel(out), sel(bw), sel(d_out))
+        dts = [torch.zeros_like(t0).index_copy_(0, active, d) for d in res[:3]]
+        return (*dts, *res[3:])
+
+    @staticmethod
+    def _backward_rows(t0, t1, t2, U, q, p, wb, w1, w2, w3, Wf, out, bw, d_out):
         n, D = t0.shape
         Dout, A, C, V = Wf.shape[1], U.shape[1], wb.shape[0], w1.shape[0]
         dev = t0.device
         lib = _lib.load()
-        d_out = d_out.contiguous()
         dts = [torch.empty_like(t0) for _ in range(3)]
         yvec = torch.empty(n, 6 * V, dtype=torch.float32, device=dev)
         dfeat = torch.empty(n, 6 * V, dtype=torch.float32, device=dev)
@@ -348,6 +370,7 @@ def neighbor_tables_device(rel, neighbor_k, seed=0):
 
 
 timing = None     # set to {} to record (start, end) events around the attention kernels (bench.py)
+_SPARSE_MIN_ROWS = 16384      # below this a backward call is too small for dropping its zero-gradient rows to pay
 
 
 def _timed(name, fn, *args):

@@ -247,3 +247,35 @@ def test_c4_size_kernels_on_sampled_nodes():
         pick = torch.randint(0, n, (2000,), device=DEV, generator=gen)
         want = TG._dense_block(torch.stack([t[pick].double() for t in ts], 1), *[x.double() for x in prm])
     np.testing.assert_allclose(got[pick].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=3e-5)
+
+
+def test_fused_dense_backward_drops_zero_gradient_rows():
+    """`_FusedDense.backward` runs its kernels on the rows with a non-zero upstream gradient only (the batch rows / their
+    sampled neighbours) and scatters the result back: same gradients as the all-rows pass."""
+    from tagrec_amd import tgcn as TG
+    n, D = 3000, 64
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: (torch.randn(*s, generator=gen) * 0.2).to(DEV)
+    A, C, V = 32, 32, 8
+    base = [rnd(n, D) for _ in range(3)] + [rnd(D, A), rnd(A), rnd(A), rnd(C, 3), rnd(V, D), rnd(V, 2 * D), rnd(V, 3 * D),
+                                           rnd(C * D + 6 * V, D), rnd(D)]
+    d_out = torch.zeros(n, D, device=DEV)
+    rows = torch.randperm(n, generator=gen)[:97].to(DEV)
+    d_out[rows] = rnd(97, D)
+    grads = []
+    old = TG._SPARSE_MIN_ROWS
+    try:
+        for thr in (10 ** 9, 0):                       # all rows, then compacted
+            TG._SPARSE_MIN_ROWS = thr
+            xs = [b.clone().requires_grad_() for b in base]
+            out = TG._FusedDense.apply(*xs, 0)
+            out.backward(d_out)
+            grads.append([x.grad.clone() for x in xs])
+    finally:
+        TG._SPARSE_MIN_ROWS = old
+    for a, b in zip(*grads):
+        scale = float(a.abs().max()) + 1e-30
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-6 * scale)
+    inactive = torch.ones(n, dtype=torch.bool, device=DEV)
+    inactive[rows] = False
+    assert float(grads[1][0][inactive].abs().max()) == 0.0
