@@ -81,6 +81,24 @@ class _NbrAttention(torch.autograd.Function):
         ws = torch.empty(ws_n, dtype=torch.float32, device=P.device)
         d_out = d_out.contiguous()
         inv = ctx.inv
+        # Row-local in d_out like the dense block: nodes whose output gradient is zero (all but the batch rows / their
+        # sampled neighbours) are dropped, and the few remaining (node, neighbour) pairs use the scatter form.
+        if n >= _SPARSE_MIN_ROWS:
+            active = torch.nonzero(d_out.abs().amax(dim=1) > 0).flatten()
+            if active.numel() * 2 < n:
+                dPc = torch.empty(active.numel(), A, dtype=torch.float32, device=P.device)
+                dQ, dEj = torch.zeros_like(Q), torch.zeros_like(Ej)
+                if active.numel() > 0:
+                    sel = lambda x: x.index_select(0, active)
+                    Pc, idxc, widxc, attnc, doc = sel(P), sel(idx), sel(widx), sel(attn), sel(d_out)
+                    _lib.check(_timed("attn_bwd", lib.tagrec_tgcn_attn_bwd_f32, _lib.ptr(Pc), _lib.ptr(Q), _lib.ptr(WT),
+                                      _lib.ptr(v), _lib.ptr(Ej), _lib.ptr(idxc), _lib.ptr(widxc), _lib.ptr(attnc), _lib.ptr(doc),
+                                      active.numel(), k, D, A, n_wt, _lib.ptr(dPc), _lib.ptr(dQ), _lib.ptr(dEj), None,
+                                      _lib.ptr(dWT), _lib.ptr(dv), _lib.ptr(ws), ws_n, _lib.stream_ptr()), "tgcn_attn_bwd")
+                else:
+                    dWT.zero_(); dv.zero_()
+                dP = torch.zeros_like(P).index_copy_(0, active, dPc)
+                return dP, dQ, dWT, dv, dEj, None, None, None
         if inv is None:                  # scatter form: float atomics into zeroed buffers
             dQ, dEj, dh = torch.zeros_like(Q), torch.zeros_like(Ej), None
         else:                            # pull form: write dh, finish with two SpMMs over the inverted table

@@ -279,3 +279,35 @@ def test_fused_dense_backward_drops_zero_gradient_rows():
     inactive = torch.ones(n, dtype=torch.bool, device=DEV)
     inactive[rows] = False
     assert float(grads[1][0][inactive].abs().max()) == 0.0
+
+
+def test_attention_backward_drops_zero_gradient_rows():
+    """`_NbrAttention.backward` on a gradient that is non-zero for a few nodes only: the compacted scatter-form pass
+    gives the gradients of the all-rows pass (pull form through the inverted table)."""
+    from tagrec_amd import tgcn as TG
+    n, n_nbr, k, D, A, n_wt = 4000, 3000, 7, 64, 32, 9
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    rnd = lambda *s: (torch.randn(*s, generator=gen) * 0.3).to(DEV)
+    idx = torch.randint(0, n_nbr + 1, (n, k), generator=gen).to(DEV)          # 0 = pad row
+    widx = torch.randint(0, n_wt, (n, k), generator=gen).to(DEV)
+    idx32, widx32 = idx.to(torch.int32), widx.to(torch.int32)
+    base = [rnd(n, A), rnd(n_nbr, A), rnd(n_wt, A), rnd(A), rnd(n_nbr, D)]              # ids are stored + 1; 0 = pad
+    d_out = torch.zeros(n, D, device=DEV)
+    rows = torch.randperm(n, generator=gen)[:61].to(DEV)
+    d_out[rows] = rnd(61, D)
+    inv = TG.InverseTable(idx32, n_nbr)
+    grads = []
+    old = TG._SPARSE_MIN_ROWS
+    try:
+        for thr, use_inv in ((10 ** 9, inv), (0, inv), (0, None)):
+            TG._SPARSE_MIN_ROWS = thr
+            xs = [b.clone().requires_grad_() for b in base]
+            out = TG.neighbour_attention(xs[0], xs[1], xs[2], xs[3], xs[4], idx32, widx32, use_inv)
+            out.backward(d_out)
+            grads.append([x.grad.clone() for x in xs])
+    finally:
+        TG._SPARSE_MIN_ROWS = old
+    for other in grads[1:]:
+        for a, b in zip(grads[0], other):
+            scale = float(a.abs().max()) + 1e-30
+            np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale)
