@@ -66,6 +66,18 @@ __global__ __launch_bounds__(kThreads) void rownorm_bwd_kernel(const float* __re
   }
 }
 
+// row_flags[r] = 1 iff row r of X [n, D] holds a non-zero
+__global__ __launch_bounds__(kThreads) void row_flags_kernel(const float* __restrict__ X, int64_t n_rows, int D,
+                                                             uint8_t* __restrict__ row_flags) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  bool nz = false;
+  for (int k = lane; k < D; k += kWave) nz |= X[r * D + k] != 0.f;
+  const bool any = __any(nz);
+  if (lane == 0) row_flags[r] = any;
+}
+
 // number of non-zero entries of a byte array (the row flags above), added to *count
 __global__ __launch_bounds__(kThreads) void count_flags_kernel(const uint8_t* __restrict__ flags, int64_t n, unsigned* __restrict__ count) {
   unsigned c = 0;
@@ -635,4 +647,15 @@ extern "C" int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p
       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), n / 4, DropMask{p, seed});
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
+}
+
+extern "C" int tagrec_row_flags_f32(const float* X, int64_t n_rows, int D, uint8_t* row_flags, unsigned* count, void* stream) {
+  TAGREC_REQUIRE(X && row_flags && count, "row_flags: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && D >= 1, "row_flags: bad shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_rows > 0) {
+    row_flags_kernel<<<static_cast<unsigned>((n_rows + 3) / 4), kThreads, 0, s>>>(X, n_rows, D, row_flags);
+    TAGREC_LAUNCH_CHECK();
+  }
+  return count_flags(row_flags, n_rows, count, s);
 }

@@ -87,7 +87,16 @@ def propagate_backward(graph_t, d_out, saved, dims):
         d_nei, d_xd, dw1, dw2 = dense_backward(dx_next, nei, x, w1p, w2p, norm=(xp, inv, d_out[:, offs[k + 1]:], dtot))
         dws[k] = (dw1, dw2)
         dx = torch.empty_like(x)
-        graph_t.spmm_axpy(d_nei, d_xd, 1.0, dx)
+        if x.shape[1] in (8, 16, 32, 64, 128, 256):
+            # d_nei is non-zero on the rows the batch gradient has reached so far (the batch rows in the last layer,
+            # their neighbours one layer down): the product does not fetch the rows flagged zero (same result)
+            flags = torch.empty(n, dtype=torch.uint8, device=x.device)
+            count = torch.zeros(1, dtype=torch.int32, device=x.device)
+            _lib.check(lib.tagrec_row_flags_f32(_lib.ptr(d_nei), n, x.shape[1], _lib.ptr(flags), _lib.ptr(count),
+                                                _lib.stream_ptr()), "row_flags")
+            graph_t.spmm_axpy_sparse(d_nei, flags, count, d_xd, 1.0, dx)
+        else:
+            graph_t.spmm_axpy(d_nei, d_xd, 1.0, dx)
         dx_next = dx
     d0 = d_out[:, :dims[0]]
     return (dx_next + d0) if dx_next is not None else d0.contiguous(), dws
