@@ -181,10 +181,13 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
     const float4 dz = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
     const float inv = e.inv_norm[r];
     const float dot = inv >= 1e12f ? 0.f : e.dot[r];
-    if (writer)
-      st_stream(reinterpret_cast<float4*>(e.Y) + off,
-                make_float4(acc.x + inv * (e.s * dz.x - xr.x * inv * dot), acc.y + inv * (e.s * dz.y - xr.y * inv * dot),
-                            acc.z + inv * (e.s * dz.z - xr.z * inv * dot), acc.w + inv * (e.s * dz.w - xr.w * inv * dot)));
+    const float4 o = make_float4(acc.x + inv * (e.s * dz.x - xr.x * inv * dot), acc.y + inv * (e.s * dz.y - xr.y * inv * dot),
+                                 acc.z + inv * (e.s * dz.z - xr.z * inv * dot), acc.w + inv * (e.s * dz.w - xr.w * inv * dot));
+    if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, o);
+    if (e.out_flags) {
+      const float nz = group_sum<LPR>((o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) ? 1.f : 0.f);
+      if (lane == 0) e.out_flags[r] = nz != 0.f;
+    }
   }
 }
 
@@ -587,4 +590,19 @@ extern "C" int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_sparse: D must be 8 .. 256, a power of two");
   EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_sparse");
+}
+
+extern "C" int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                                  const unsigned* in_count, const float* X_raw, const float* inv_norm,
+                                                  const float* dZ, const float* dot, float d_scale, float* G_out,
+                                                  uint8_t* out_flags, unsigned* out_count, int D, void* stream) {
+  TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr && dot != nullptr,
+                 "spmm_normbwd_dot_sparse: null X_raw, inv_norm, dZ or dot");
+  TAGREC_REQUIRE(in_flags != nullptr && in_count != nullptr, "spmm_normbwd_dot_sparse: null in_flags or in_count");
+  TAGREC_REQUIRE((out_flags == nullptr) == (out_count == nullptr), "spmm_normbwd_dot_sparse: out_flags and out_count go together");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_normbwd_dot_sparse: D must be 8 .. 256, a power of two");
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, in_flags, in_count, out_flags};
+  int rc = launch_spmm<EPI_NORMBWD_DOT>(g, G_in, e, D, stream, "spmm_normbwd_dot_sparse");
+  if (rc != TAGREC_OK || !out_flags) return rc;
+  return count_flags(out_flags, g->n_rows, out_count, static_cast<hipStream_t>(stream));
 }

@@ -96,6 +96,27 @@ class HipOps:
                                                           _lib.ptr(out), x.shape[0], x.shape[1], _lib.stream_ptr()),
                    "rownorm_bwd_dot")
 
+    # -- row-sparse gradients (the batch gradient reaches a few rows per hop; see EpiArgs::in_flags in csrc/spmm.hip)
+    sparse_backward = True
+
+    def row_flags(self, x):
+        flags = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+        count = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _lib.check(_lib.load().tagrec_row_flags_f32(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(flags), _lib.ptr(count),
+                                                    _lib.stream_ptr()), "row_flags")
+        return flags, count
+
+    def spmm_normbwd_dot_sparse(self, g, g_in, fl, x_raw, inv, dz, dot, s, out):
+        out_flags = torch.empty(out.shape[0], dtype=torch.uint8, device=out.device)
+        out_count = torch.zeros(1, dtype=torch.int32, device=out.device)
+        g._call("spmm_normbwd_dot", _lib.load().tagrec_spmm_normbwd_dot_sparse_f32, g.handle, _lib.ptr(g_in), _lib.ptr(fl[0]),
+                _lib.ptr(fl[1]), _lib.ptr(x_raw), _lib.ptr(inv), _lib.ptr(dz), _lib.ptr(dot), float(s), _lib.ptr(out),
+                _lib.ptr(out_flags), _lib.ptr(out_count), g_in.shape[1], _lib.stream_ptr())
+        return out_flags, out_count
+
+    def spmm_axpy_sparse(self, g, g_in, fl, b, s, out):
+        g.spmm_axpy_sparse(g_in, fl[0], fl[1], b, s, out)
+
     def bpr_dots(self, U, I, Ur, Ir, trip):
         B, D = trip.shape[0], U.shape[1]
         dots = torch.empty(B, 3, dtype=torch.float32, device=U.device)
@@ -309,12 +330,21 @@ class _FeatureShardedLoss(torch.autograd.Function):
             m.all_reduce(dots)                                      # every layer's z . (s dZ), one collective
             gl = torch.empty_like(d_out)
             m.ops.rownorm_bwd_dot(raws[L - 1], invs[L - 1], d_out, dots[L - 1], s, gl)
+            # the gradient spreads from the batch rows by one hop per product: rows still zero are not gathered
+            sparse = getattr(m.ops, "sparse_backward", False) and x0.shape[1] in (8, 16, 32, 64, 128, 256)
+            fl = m.ops.row_flags(gl) if sparse else None
             for k in range(L - 2, -1, -1):
                 gn = torch.empty_like(d_out)
-                m.ops.spmm_normbwd_dot(m.graph, gl, raws[k], invs[k], d_out, dots[k], s, gn)
+                if sparse:
+                    fl = m.ops.spmm_normbwd_dot_sparse(m.graph, gl, fl, raws[k], invs[k], d_out, dots[k], s, gn)
+                else:
+                    m.ops.spmm_normbwd_dot(m.graph, gl, raws[k], invs[k], d_out, dots[k], s, gn)
                 gl = gn
             g0 = torch.empty_like(d_out)
-            m.ops.spmm_axpy(m.graph, gl, d_out, s, g0)
+            if sparse:
+                m.ops.spmm_axpy_sparse(m.graph, gl, fl, d_out, s, g0)
+            else:
+                m.ops.spmm_axpy(m.graph, gl, d_out, s, g0)
         if m.reg != 0:
             m.ops.bpr_bwd(U, I, Ue, Ie, trip, ctx.coef, g, None, None, g0[:nu], g0[nu:nu + ni])
         ctx.raws = ctx.invs = ctx.out = None
