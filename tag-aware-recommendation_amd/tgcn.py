@@ -318,6 +318,41 @@ class _Layer(nn.Module):
         return outs
 
 
+    def forward_rows(self, emb, ewp, nbr, rows_out, rows_in, chunk_rows, use_checkpoint, fused=True, inv=None):
+        """`forward` restricted to the rows a mini-batch's loss depends on.  emb[t]: full-size input tables, valid on
+        rows_in[t] (None = every row); rows_out[t]: rows whose outputs are wanted (None = every row; a subset of
+        rows_in[t]).  Returns {type: outputs of those rows, in that order}."""
+        D = self.in_features
+        inv = inv if inv is not None else [None] * 6
+        others = {"user": ("item", "tag"), "item": ("user", "tag"), "tag": ("user", "item")}
+        A = self.U.shape[1]
+        pick = lambda x, rows: x if rows is None else x.index_select(0, rows)
+        Q, P, selfv = {}, {}, {}
+        for t, (n1, n2) in others.items():
+            # Q_t = e_t W2 is read wherever t is the NEIGHBOUR type: needed on rows_in[t]
+            q = pick(emb[t], rows_in[t]) @ self.atten1[t].W_2
+            Q[t] = q if rows_in[t] is None else q.new_zeros(emb[t].shape[0], A).index_copy_(0, rows_in[t], q)
+            selfv[t] = pick(emb[t], rows_out[t])
+            y = selfv[t] @ torch.cat([self.atten1[n1].W_1[:D], self.atten1[n2].W_1[:D]], dim=1)
+            P[(t, n1)] = y[:, :A] + self.atten1[n1].b
+            P[(t, n2)] = y[:, A:] + self.atten1[n2].b
+        WT = {t: ewp @ self.atten1[t].W_1[D:] for t in emb}
+
+        def att(src, nb, r):
+            a = self.atten1[nb]
+            rows = rows_out[src]
+            idx, widx = pick(nbr[r][0], rows), pick(nbr[r][1], rows)
+            return neighbour_attention(P[(src, nb)].contiguous(), Q[nb], WT[nb], a.v.reshape(-1), emb[nb], idx, widx,
+                                       inv[r] if rows is None else None)
+
+        eu_i, eu_t = att("user", "item", 0), att("user", "tag", 1)
+        ei_u, ei_t = att("item", "user", 2), att("item", "tag", 3)
+        et_u, et_i = att("tag", "user", 4), att("tag", "item", 5)
+        trips = {"user": (selfv["user"], eu_i, eu_t), "item": (ei_u, selfv["item"], ei_t), "tag": (et_u, et_i, selfv["tag"])}
+        return {t: (self.dense(trip, chunk_rows, use_checkpoint, fused) if trip[0].shape[0] > 0
+                    else trip[0].new_zeros(0, self.Wf.shape[1])) for t, trip in trips.items()}
+
+
 def neighbor_tables(data, neighbor_k, seed=0):
     """First-`neighbor_k`-column semantics of the reference's tables (data/tgcn_load.py:41-53 +
     data/utils.py:87-106 + model/tgcn.py:199) without materialising (n, max_deg): per row of each of the
@@ -410,6 +445,7 @@ class TGCN(nn.Module):
             raise _lib.TagrecError("TGCN: tagrec_amd needs a GPU device (no CPU path)")
         _lib.load()
         self.num_user, self.num_item, self.num_tag = data.num["user"], data.num["item"], data.num["tag"]
+        self.prune_forward = self._prune_cfg[0] and (self.num_user + self.num_item + self.num_tag) >= self._prune_cfg[1]
         self.num_weight = data.num["weight"]
         # parameters: same construction and registration order as tgcn.py:173-192 (RNG parity)
         self.embed = nn.ParameterDict({
@@ -459,6 +495,9 @@ class TGCN(nn.Module):
         self.margin = config["margin"]
         self.seed = config.get("seed", 2020)
         self.chunk_rows = config.get("tgcn_chunk_rows", 65536)
+        # loss(): run every layer only on the rows the batch's loss depends on (see _forward_rows); off below
+        # config["tgcn_prune_min_nodes"] nodes, where the bookkeeping costs more than it saves
+        self._prune_cfg = (bool(config.get("tgcn_prune_forward", True)), config.get("tgcn_prune_min_nodes", 200_000))
         self.use_checkpoint = config.get("tgcn_checkpoint", True)
         self.fused_dense = config.get("tgcn_fused_dense", True)
         self.pull_backward = config.get("tgcn_pull_backward", True)
@@ -484,9 +523,77 @@ class TGCN(nn.Module):
     def get_ego_embed(self):
         return self.embed["user"], self.embed["item"], self.embed["tag"]
 
+    # relation r = (source type, neighbour type), in the order of the neighbour tables (ui, ut, iu, it, tu, ti)
+    _RELATIONS = (("user", "item"), ("user", "tag"), ("item", "user"), ("item", "tag"), ("tag", "user"), ("tag", "item"))
+
+    def _needed_rows(self, batch):
+        """need[l][t]: the rows of layer l's output (l = 1..L; type t) that the loss of `batch` depends on -- the batch
+        rows at the top, plus, one layer down, their k sampled neighbours under every relation -- or None once a type
+        needs more than half of its rows (then all of them are computed)."""
+        sizes = {"user": self.num_user, "item": self.num_item, "tag": self.num_tag}
+        L = len(self.layer)
+        top = {"user": torch.unique(batch[:, 0]), "item": torch.unique(batch[:, 1:]),
+               "tag": torch.empty(0, dtype=torch.int64, device=self.device)}
+        need = [None] * (L + 1)
+        need[L] = top
+        for l in range(L, 1, -1):
+            cur = need[l]
+            masks = {}
+            for t, n in sizes.items():                               # slot 0 absorbs the pad index of the tables
+                m = torch.zeros(n + 1, dtype=torch.bool, device=self.device)
+                if cur[t] is None:
+                    m[1:] = True
+                elif cur[t].numel():
+                    m[cur[t] + 1] = True
+                masks[t] = m
+            for r, (src, nb) in enumerate(self._RELATIONS):
+                if cur[src] is None:
+                    masks[nb][self.nbr[r][0].long().flatten()] = True
+                elif cur[src].numel():
+                    masks[nb][self.nbr[r][0].index_select(0, cur[src]).long().flatten()] = True
+            nxt = {}
+            for t, n in sizes.items():
+                rows = torch.nonzero(masks[t][1:]).flatten()
+                nxt[t] = None if rows.numel() * 2 > n else rows
+            need[l - 1] = nxt
+        return need
+
+    def _forward_rows(self, batch):
+        """The forward pass restricted, layer by layer, to `_needed_rows`: identical outputs on the batch rows (the
+        only rows the loss reads), zeros elsewhere.  Bounded fan-in (k sampled neighbours) is what makes this pay
+        for TGCN: the top layer runs on the <= 3 B batch rows, the one below on <= 2 k of those per row."""
+        need = self._needed_rows(batch)
+        ew = self.embed["weight"]
+        ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])
+        emb = {"user": self.embed["user"], "item": self.embed["item"], "tag": self.embed["tag"]}
+        cat = {t: [e] for t, e in emb.items()}
+        rows_in = {t: None for t in emb}
+        for i, layer in enumerate(self.layer.values()):
+            rows_out = need[i + 1]
+            outs = layer.forward_rows(emb, ewp, self.nbr, rows_out, rows_in, self.chunk_rows, self.use_checkpoint,
+                                      self.fused_dense, self.inv)
+            p = self.message_drop_list[i]
+            nxt = {}
+            for t, o in outs.items():
+                if self.training and p > 0:
+                    o = torch.nn.functional.dropout(o, p=p, training=True)
+                z = H.normalize_rows(o) if o.shape[0] else o
+                if rows_out[t] is None:
+                    nxt[t] = o
+                    cat[t].append(z)
+                else:
+                    n = emb[t].shape[0]
+                    nxt[t] = o.new_zeros(n, o.shape[1]).index_copy_(0, rows_out[t], o)
+                    cat[t].append(z.new_zeros(n, z.shape[1]).index_copy_(0, rows_out[t], z))
+            emb, rows_in = nxt, rows_out
+        return torch.cat(cat["user"], dim=1), torch.cat(cat["item"], dim=1)
+
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
-        all_users, all_items = self.forward()[:2]
+        if self.prune_forward and self.training:
+            all_users, all_items = self._forward_rows(batch_data)
+        else:
+            all_users, all_items = self.forward()[:2]
         loss, reg_loss = H.triplet_loss(all_users, all_items, all_users, all_items, batch_data, self.loss_func)
         return loss, self.reg * reg_loss
 

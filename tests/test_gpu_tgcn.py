@@ -311,3 +311,31 @@ def test_attention_backward_drops_zero_gradient_rows():
         for a, b in zip(grads[0], other):
             scale = float(a.abs().max()) + 1e-30
             np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale)
+
+
+def test_pruned_forward_gives_the_full_forward_loss_and_gradients():
+    """`TGCN.loss` with the layers restricted to the rows the batch's loss depends on (`_forward_rows`) vs the full
+    forward: same loss parts, same gradient of every parameter."""
+    ds = T.synth.make_cf_dataset(900, 700, 9000, seed=21, n_tag=300, n_assign=7000)
+    cfg = T.get_config("tgcn", dim_layer_list=[32, 32, 32], dim_latent=32, device=DEV, neighbor_k=4, train_batch=24, reg=1e-3)
+    torch.manual_seed(4)
+    m = T.TGCN(ds, config=cfg)
+    m.train()
+    batch = torch.from_numpy(T.synth.sample_bpr_epoch(ds, 3)[:24]).to(DEV)
+    need = m._needed_rows(batch)
+    assert need[3]["tag"].numel() == 0 and need[3]["user"].numel() <= 24
+    assert all(need[2][t] is None or need[2][t].numel() < need[1][t].numel() if need[1][t] is not None else True
+               for t in ("user", "item", "tag"))
+    out = []
+    for prune in (False, True):
+        m.prune_forward = prune
+        m.zero_grad()
+        lossx = m.loss(batch)
+        sum(lossx).backward()
+        out.append(([float(v) for v in lossx], {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = out
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    assert set(g0) == set(g1)
+    for k in g0:
+        scale = float(g0[k].abs().max()) + 1e-30
+        np.testing.assert_allclose(g1[k].cpu().numpy(), g0[k].cpu().numpy(), rtol=1e-4, atol=2e-6 * scale, err_msg=k)
