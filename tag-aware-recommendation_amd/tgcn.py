@@ -341,6 +341,8 @@ class _Layer(nn.Module):
         def att(src, nb, r):
             a = self.atten1[nb]
             rows = rows_out[src]
+            if rows is not None and rows.numel() == 0:
+                return emb[nb].new_zeros(0, D)
             idx, widx = pick(nbr[r][0], rows), pick(nbr[r][1], rows)
             return neighbour_attention(P[(src, nb)].contiguous(), Q[nb], WT[nb], a.v.reshape(-1), emb[nb], idx, widx,
                                        inv[r] if rows is None else None)
