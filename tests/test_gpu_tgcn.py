@@ -338,8 +338,13 @@ def test_pruned_forward_gives_the_full_forward_loss_and_gradients():
     assert set(g0) == set(g1)
     # sums over nodes run over different row sets / orders in the two passes (and the compact attention backward uses
     # float atomics): compare tensors as a whole
-    worst = {}
+    worst, norms = {}, {}
     for k in g0:
         a, b = g0[k].double(), g1[k].double()
-        worst[k] = float((a - b).norm() / (a.norm() + 1e-300))
-    assert max(worst.values()) <= 2e-3, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+        norms[k] = float(a.norm())
+        worst[k] = float((a - b).norm())
+    top = max(norms.values())
+    # per tensor: relative to its own norm, with a floor at 1e-5 of the largest gradient norm (tensors whose gradient
+    # is pure cancellation noise -- the top layer's attention parameters at this tiny scale -- cannot be compared tighter)
+    bad = {k: (worst[k], norms[k]) for k in g0 if worst[k] > 2e-3 * max(norms[k], 1e-5 * top)}
+    assert not bad, (top, sorted(bad.items(), key=lambda kv: -kv[1][0])[:6])
