@@ -344,7 +344,7 @@ def test_pruned_forward_gives_the_full_forward_loss_and_gradients():
         norms[k] = float(a.norm())
         worst[k] = float((a - b).norm())
     top = max(norms.values())
-    # per tensor: relative to its own norm, with a floor at 1e-5 of the largest gradient norm (tensors whose gradient
-    # is pure cancellation noise -- the top layer's attention parameters at this tiny scale -- cannot be compared tighter)
-    bad = {k: (worst[k], norms[k]) for k in g0 if worst[k] > 2e-3 * max(norms[k], 1e-5 * top)}
+    # per tensor: relative to its own norm, plus fp32 accumulation noise at the scale of the largest gradient (the top
+    # layer's parameter gradients are ~1e-8 here, sums of +-1e-3 terms that cancel: both passes carry ~1e-8 of noise)
+    bad = {k: (worst[k], norms[k]) for k in g0 if worst[k] > 2e-3 * norms[k] + 2e-6 * top}
     assert not bad, (top, sorted(bad.items(), key=lambda kv: -kv[1][0])[:6])
