@@ -348,3 +348,39 @@ def test_pruned_forward_gives_the_full_forward_loss_and_gradients():
     # layer's parameter gradients are ~1e-8 here, sums of +-1e-3 terms that cancel: both passes carry ~1e-8 of noise)
     bad = {k: (worst[k], norms[k]) for k in g0 if worst[k] > 2e-3 * norms[k] + 2e-6 * top}
     assert not bad, (top, sorted(bad.items(), key=lambda kv: -kv[1][0])[:6])
+
+
+def test_pruned_and_row_sparse_step_equals_full_step_at_mid_scale():
+    """A 200 k-node tripartite graph (D = 64, k = 25, L = 3), where both shortcuts switch on by themselves: the loss and
+    the embedding gradients of the restricted step (needed rows only in the forward, non-zero-gradient rows only in the
+    backward) against the all-rows step."""
+    from tagrec_amd import tgcn as TG
+    ds = T.synth.make_tripartite_device(50_000, 50_000, 100_000, 3_000_000, seed=6, device=DEV)
+    cfg = T.get_config("tgcn", dim_latent=64, dim_layer_list=[64, 64, 64], device=DEV, train_batch=256, neighbor_k=25, reg=1e-4)
+    torch.manual_seed(1)
+    m = T.TGCN(ds, config=cfg)
+    m.train()
+    assert m.prune_forward
+    prod = T.BPR_training_data(ds, config=cfg, seed=5)
+    batch = prod.all_train_data[:256]
+    need = m._needed_rows(batch)
+    assert need[3]["user"].numel() <= 256 and need[2]["item"] is not None and need[2]["item"].numel() < 25_000
+    res = []
+    old = TG._SPARSE_MIN_ROWS
+    try:
+        for restricted in (False, True):
+            m.prune_forward = restricted
+            TG._SPARSE_MIN_ROWS = old if restricted else 10 ** 12
+            m.zero_grad()
+            lossx = m.loss(batch)
+            sum(lossx).backward()
+            res.append(([float(v) for v in lossx], {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        TG._SPARSE_MIN_ROWS = old
+        m.prune_forward = True
+    (l0, g0), (l1, g1) = res
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)
+    top = max(float(g.double().norm()) for g in g0.values())
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 2e-6 * top, k
