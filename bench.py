@@ -302,6 +302,15 @@ def main():
     extra = {"graph_build_s": round(t_build, 2), "epoch_sampling_s": round(t_sample, 3),
              "epoch_triplets": int(epoch.shape[0]), "last_loss": loss_val,
              "edge_layers_per_s": nnz * L * 2 * K / dt}
+    if args.model == "lightgcn" and not sharded and getattr(model, "restrict_forward", False):
+        # the same step with every forward layer computed on ALL rows (the timed step above computes the top two
+        # layers only on the rows the batch's loss depends on -- same loss and gradients)
+        model.restrict_forward = False
+        run_steps(batches[:W])
+        dtf, _ = timed(batches[W:])
+        model.restrict_forward = True
+        extra["ms_per_step_all_rows_forward"] = dtf / K * 1e3
+        extra["triplets_per_s_all_rows_forward"] = K * B / dtf
     if args.big_batch and epoch.shape[0] >= args.big_batch * 3 and not sharded:
         BB = args.big_batch
         bb = [epoch[k * BB:(k + 1) * BB] for k in range(3)]

@@ -111,6 +111,16 @@ int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float* G_in, con
 int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                 const unsigned* in_count, const float* B, float b_scale, float* G_out, int D,
                                 void* stream);
+/* Forward layer on a SUBSET of the output rows.  The loss reads the propagated table at the batch rows only
+ * (model/lightgcn.py:71-75), so the last layer is needed on those rows and the layer below it on their neighbours.
+ *   graph_mark_rows   : flags[c] = 1 for every column index stored in the listed rows and for the rows themselves
+ *                       (flags uint8 [n_rows], zeroed / pre-marked by the caller; square adjacency)
+ *   spmm_norm_acc_rows: tagrec_spmm_norm_acc_drop_f32 for the rows with row_mask[r] != 0; the other rows of Y_raw,
+ *                       inv_norm and acc are left untouched */
+int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, uint8_t* flags, void* stream);
+int tagrec_spmm_norm_acc_rows_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
+                                  float* acc, float acc_scale, const uint8_t* row_mask, float drop_p,
+                                  uint64_t seed, int D, void* stream);
 /* tagrec_spmm_normbwd_dot_f32 (column-sharded tables) on a row-sparse G_in */
 int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                        const unsigned* in_count, const float* X_raw, const float* inv_norm,

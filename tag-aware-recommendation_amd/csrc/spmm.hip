@@ -46,6 +46,10 @@ struct EpiArgs {
   const uint8_t* in_flags;
   const unsigned* in_count;
   uint8_t* out_flags;
+  // Output rows to compute (NORM_ACC): row r is skipped entirely when row_mask[r] == 0 -- its outputs are neither
+  // written nor accumulated.  nullptr = every row.  The last forward layer is needed on the batch rows only and the one
+  // before it on their neighbours (lightgcn.py: the loss reads `out` at the batch rows).
+  const uint8_t* row_mask;
 };
 
 // Streamed-once data (indices, values, epilogue operands, outputs) is moved with non-temporal accesses so it does
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
     if (c >= lv.n_chunks) return;
     const int2 d = lv.chunk_desc[c];
     const int64_t r = lv.long_rows[d.x];
+    if (e.row_mask && !e.row_mask[r]) return;
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
     const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
@@ -213,6 +218,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
   }
   const int64_t r = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
   if (r >= g.n_rows) return;
+  if (e.row_mask && !e.row_mask[r]) return;
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
   if (end - start > kLongRow) return;  // chunked above, folded by spmm_finish_kernel
   const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_rows);
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_finish_kernel(Gra
   const int64_t li = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
   if (li >= n_long) return;
   const int64_t r = long_rows[li];
+  if (e.row_mask && !e.row_mask[r]) return;
   const int64_t deg = g.rowptr[r + 1] - g.rowptr[r];
   const int nc = static_cast<int>((deg + kChunk - 1) / kChunk);
   const float4* p = reinterpret_cast<const float4*>(slab) + static_cast<int64_t>(long_base[li]) * LPR + (lane % LPR);
@@ -336,6 +343,16 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_generic_kern
       if (k < D) e.Y[row + k] = acc[b] + inv * (e.s * e.B[row + k] - e.Xraw[row + k] * inv * dot);
     }
   }
+}
+
+// flags[c] = 1 for every column index stored in the listed rows, and for the rows themselves (block per listed row)
+__global__ __launch_bounds__(256) void mark_rows_kernel(GraphView g, const int64_t* __restrict__ rows, int64_t n_listed,
+                                                        uint8_t* __restrict__ flags) {
+  const int64_t i = blockIdx.x;
+  if (i >= n_listed) return;
+  const int64_t r = rows[i];
+  if (threadIdx.x == 0) flags[r] = 1;
+  for (int64_t j = g.rowptr[r] + threadIdx.x; j < g.rowptr[r + 1]; j += blockDim.x) flags[g.col[j]] = 1;
 }
 
 // ---- row-length scan at graph creation ---------------------------------------------------------
@@ -505,14 +522,14 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
 }  // namespace
 
 extern "C" int tagrec_spmm_f32(const tagrec_graph* g, const float* X, float* Y, int D, void* stream) {
-  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
+  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NONE>(g, X, e, D, stream, "spmm");
 }
 
 extern "C" int tagrec_spmm_norm_acc_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
                                         float* acc, float acc_scale, int D, void* stream) {
   TAGREC_REQUIRE(inv_norm != nullptr && acc != nullptr, "spmm_norm_acc: null inv_norm or acc");
-  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc");
 }
 
@@ -520,20 +537,20 @@ extern "C" int tagrec_spmm_normbwd_f32(const tagrec_graph* g, const float* G_in,
                                        const float* inv_norm, const float* dZ, float d_scale, float* G_out,
                                        int D, void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr, "spmm_normbwd: null X_raw, inv_norm or dZ");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd");
 }
 
 extern "C" int tagrec_spmm_axpy_f32(const tagrec_graph* g, const float* G_in, const float* B, float b_scale,
                                     float* G_out, int D, void* stream) {
   TAGREC_REQUIRE(B != nullptr, "spmm_axpy: null B");
-  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy");
 }
 
 extern "C" int tagrec_spmm_ss_f32(const tagrec_graph* g, const float* X, float* Y, float* ss, int D, void* stream) {
   TAGREC_REQUIRE(ss != nullptr, "spmm_ss: null ss");
-  EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
+  EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_SS>(g, X, e, D, stream, "spmm_ss");
 }
 
@@ -542,7 +559,7 @@ extern "C" int tagrec_spmm_normbwd_dot_f32(const tagrec_graph* g, const float* G
                                            float* G_out, int D, void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr && dot != nullptr,
                  "spmm_normbwd_dot: null X_raw, inv_norm, dZ or dot");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORMBWD_DOT>(g, G_in, e, D, stream, "spmm_normbwd_dot");
 }
 
@@ -552,7 +569,7 @@ extern "C" int tagrec_spmm_norm_acc_drop_f32(const tagrec_graph* g, const float*
   TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_norm_acc_drop: p must be in [0, 1)");
   TAGREC_REQUIRE(drop_p == 0.f || (D % 4 == 0 && D <= 256 && (D & (D - 1)) == 0 && D >= 8),
                  "spmm_norm_acc_drop: dropout needs a vector-kernel width (8..256, power of two)");
-  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr};
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc_drop");
 }
 
@@ -563,7 +580,7 @@ extern "C" int tagrec_spmm_normbwd_drop_f32(const tagrec_graph* g, const float* 
   TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_normbwd_drop: p must be in [0, 1)");
   TAGREC_REQUIRE(drop_p == 0.f || (D % 4 == 0 && D <= 256 && (D & (D - 1)) == 0 && D >= 8),
                  "spmm_normbwd_drop: dropout needs a vector-kernel width (8..256, power of two)");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd_drop");
 }
 
@@ -577,7 +594,7 @@ extern "C" int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float
   TAGREC_REQUIRE((out_flags == nullptr) == (out_count == nullptr), "spmm_normbwd_sparse: out_flags and out_count go together");
   TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_normbwd_sparse: p must be in [0, 1)");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_normbwd_sparse: D must be 8 .. 256, a power of two");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}, in_flags, in_count, out_flags};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}, in_flags, in_count, out_flags, nullptr};
   int rc = launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd_sparse");
   if (rc != TAGREC_OK || !out_flags) return rc;
   return count_flags(out_flags, g->n_rows, out_count, static_cast<hipStream_t>(stream));
@@ -588,7 +605,7 @@ extern "C" int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G
                                            void* stream) {
   TAGREC_REQUIRE(B != nullptr && in_flags != nullptr && in_count != nullptr, "spmm_axpy_sparse: null B, in_flags or in_count");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_sparse: D must be 8 .. 256, a power of two");
-  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr};
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, nullptr};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_sparse");
 }
 
@@ -601,8 +618,31 @@ extern "C" int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const f
   TAGREC_REQUIRE(in_flags != nullptr && in_count != nullptr, "spmm_normbwd_dot_sparse: null in_flags or in_count");
   TAGREC_REQUIRE((out_flags == nullptr) == (out_count == nullptr), "spmm_normbwd_dot_sparse: out_flags and out_count go together");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_normbwd_dot_sparse: D must be 8 .. 256, a power of two");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, in_flags, in_count, out_flags};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, in_flags, in_count, out_flags, nullptr};
   int rc = launch_spmm<EPI_NORMBWD_DOT>(g, G_in, e, D, stream, "spmm_normbwd_dot_sparse");
   if (rc != TAGREC_OK || !out_flags) return rc;
   return count_flags(out_flags, g->n_rows, out_count, static_cast<hipStream_t>(stream));
+}
+
+// ---- forward layer on a subset of the output rows -------------------------------------------------------------------
+extern "C" int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, uint8_t* flags,
+                                         void* stream) {
+  TAGREC_REQUIRE(g != nullptr && flags != nullptr && (n_listed == 0 || rows != nullptr), "graph_mark_rows: null pointer");
+  TAGREC_REQUIRE(g->n_rows == g->n_cols, "graph_mark_rows: square adjacency expected (flags are indexed by node)");
+  TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "graph_mark_rows: bad row count");
+  if (n_listed == 0) return TAGREC_OK;
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  mark_rows_kernel<<<static_cast<unsigned>(n_listed), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_spmm_norm_acc_rows_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
+                                             float* acc, float acc_scale, const uint8_t* row_mask, float drop_p,
+                                             uint64_t seed, int D, void* stream) {
+  TAGREC_REQUIRE(inv_norm != nullptr && acc != nullptr && row_mask != nullptr, "spmm_norm_acc_rows: null inv_norm, acc or row_mask");
+  TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_norm_acc_rows: p must be in [0, 1)");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_norm_acc_rows: D must be 8 .. 256, a power of two");
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr, row_mask};
+  return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc_rows");
 }

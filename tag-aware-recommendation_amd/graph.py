@@ -261,6 +261,20 @@ class Graph:
         self._call("spmm_norm_acc", _lib.load().tagrec_spmm_norm_acc_f32, self._h, _lib.ptr(X), _lib.ptr(y_raw),
                    _lib.ptr(inv_norm), _lib.ptr(acc), float(acc_scale), D, _lib.stream_ptr())
 
+    def mark_rows(self, rows, flags):
+        """flags[c] = 1 for every column stored in `rows` (int64 node ids) and for the rows themselves."""
+        rows = rows.contiguous()
+        _lib.check(_lib.load().tagrec_graph_mark_rows_u8(self._h, _lib.ptr(rows), rows.numel(), _lib.ptr(flags),
+                                                         _lib.stream_ptr()), "graph_mark_rows")
+        return flags
+
+    def spmm_norm_acc_rows(self, X, y_raw, inv_norm, acc, acc_scale, row_mask, drop_p=0.0, seed=0):
+        """`spmm_norm_acc` for the rows with row_mask[r] != 0 only (the others are left as they are)."""
+        D = self._chk_x(X, self.shape[1], "spmm_norm_acc X")
+        self._call("spmm_norm_acc_rows", _lib.load().tagrec_spmm_norm_acc_rows_f32, self._h, _lib.ptr(X), _lib.ptr(y_raw),
+                   _lib.ptr(inv_norm), _lib.ptr(acc), float(acc_scale), _lib.ptr(row_mask), float(drop_p), int(seed), D,
+                   _lib.stream_ptr())
+
     def spmm_normbwd(self, g_in, x_raw, inv_norm, dz, d_scale, g_out, drop_p=0.0, seed=0):
         D = self._chk_x(g_in, self.shape[1], "spmm_normbwd g_in")
         for t, nm in ((x_raw, "x_raw"), (dz, "dz"), (g_out, "g_out")):

@@ -25,15 +25,35 @@ def _layer_seed(seed, k):
     return (int(seed) * 64 + k) & 0xFFFFFFFFFFFFFFFF
 
 
-def propagate_forward(graph, x0, n_layer, drops=None, seed=0):
+def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None):
     """x0 -> (out, raws, invs): out = mean(x0, z1..zL), raws[k] = dropout(A raws[k-1]) (un-normalised),
     invs[k][r] = 1/max(||raws[k][r]||, 1e-12).  One fused kernel per layer.  drops[k] > 0 = message dropout of
-    layer k's product (lightgcn.py:56), drawn inside the kernel from (seed, layer, element)."""
+    layer k's product (lightgcn.py:56), drawn inside the kernel from (seed, layer, element).
+
+    loss_rows (int64 node ids): `out` will be read at these rows only (the batch rows of the BPR loss).  Then the last
+    layer is computed on them alone and the layer below it on their neighbours (anything further down reaches nearly
+    every node through the popular items, so it runs in full); the rows left out stay zero in raws / invs and are
+    never read with a non-zero gradient in the backward pass.  Needs a symmetric graph of a vector-kernel width."""
     s = 1.0 / (n_layer + 1)
     out = x0 * s
     raws, invs = [], []
     x = x0
+    masks = {}
+    if loss_rows is not None and n_layer >= 1 and graph.symmetric and x0.shape[1] in (8, 16, 32, 64, 128, 256):
+        top = torch.zeros(x0.shape[0], dtype=torch.uint8, device=x0.device)
+        top[loss_rows] = 1
+        masks[n_layer - 1] = top
+        if n_layer >= 2:
+            masks[n_layer - 2] = graph.mark_rows(loss_rows, torch.zeros_like(top))
     for k in range(n_layer):
+        if k in masks:
+            y = torch.zeros_like(x0)
+            inv = torch.zeros(x0.shape[0], dtype=torch.float32, device=x0.device)
+            graph.spmm_norm_acc_rows(x, y, inv, out, s, masks[k], drops[k] if drops else 0.0, _layer_seed(seed, k))
+            raws.append(y)
+            invs.append(inv)
+            x = y
+            continue
         y = torch.empty_like(x0)
         inv = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
         graph.spmm_norm_acc(x, y, inv, out, s, drops[k] if drops else 0.0, _layer_seed(seed, k))
@@ -106,9 +126,12 @@ class _PropagateBprLoss(torch.autograd.Function):
     """table -> [mul_loss, l2reg_loss(ego rows)] in one autograd node."""
 
     @staticmethod
-    def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active, drops=None, seed=0):
+    def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active, drops=None, seed=0, restrict=True):
         x0 = table.detach()
-        out, raws, invs = propagate_forward(graph, x0, n_layer, drops, seed)
+        loss_rows = None
+        if restrict:                     # the loss reads `out` at the batch rows only: users, and items offset by n_user
+            loss_rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user])
+        out, raws, invs = propagate_forward(graph, x0, n_layer, drops, seed, loss_rows)
         ctx.drops, ctx.seed = drops, seed
         B, D = trip.shape[0], x0.shape[1]
         coef = torch.empty(B, dtype=torch.float32, device=x0.device)
@@ -146,7 +169,7 @@ class _PropagateBprLoss(torch.autograd.Function):
                                               null, null, _lib.ptr(g0[:nu]), _lib.ptr(g0[nu:nu + ni]),
                                               _lib.stream_ptr()), "bpr_bwd(reg)")
         ctx.raws = ctx.invs = ctx.out = None
-        return g0, None, None, None, None, None, None, None, None, None
+        return g0, None, None, None, None, None, None, None, None, None, None
 
 
 class LightGCN(TableModel):
@@ -169,6 +192,8 @@ class LightGCN(TableModel):
         self.message_drop_list = config["message_drop_list"]
         self.node_drop = config["node_drop"]
         self.drop_seed = config.get("seed", 2020)
+        # loss(): compute the top two layers only on the rows the batch's loss depends on (propagate_forward)
+        self.restrict_forward = bool(config.get("restrict_forward", True))
 
     def _fused_ok(self):
         return isinstance(self.norm_adj, Graph)
@@ -213,7 +238,7 @@ class LightGCN(TableModel):
         if self._fused_ok():
             drops, seed = self._drops()
             res = _PropagateBprLoss.apply(self.table, self._graph(), self.num_layer, nu, ni, batch_data,
-                                          H.loss_kind_id(self.loss_func), self.reg != 0, drops, seed)
+                                          H.loss_kind_id(self.loss_func), self.reg != 0, drops, seed, self.restrict_forward)
             return res[0], self.reg * res[1]
         all_users, all_items = self.forward()[:2]
         ego = self.embed

@@ -357,3 +357,30 @@ def test_feature_shard_kernels_compose_to_full_width(golden, G):
     u, p_, n_ = x[:nu][trip[:, 0]], x[nu:nu + ni][trip[:, 1]], x[nu:nu + ni][trip[:, 2]]
     want = torch.stack([(u * p_).sum(1), (u * n_).sum(1), 0.5 * (u.pow(2).sum(1) + p_.pow(2).sum(1) + n_.pow(2).sum(1))], 1)
     np.testing.assert_allclose(dots.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_restricted_forward_equals_full_forward_step():
+    """`LightGCN.loss` computes the top two layers only on the rows the batch's loss depends on (batch rows; their
+    neighbours one layer down): same loss parts and the same table gradient as with every layer on all rows, on a graph
+    with long rows (popular items) so that the chunked path is masked too."""
+    ds = T.synth.make_bipartite_device(30_000, 20_000, 1_500_000, seed=3, device=DEV)
+    e = ds.edge_index["train"]
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 30_000, 20_000, "bi_norm")
+    g = T.Graph(rp, col, val, (n, n), symmetric=True)
+    assert g.info()["n_long_rows"] > 0
+    cfg = T.get_config("lightgcn", use_tag=False, dim_latent=64, dim_layer_list=[64] * 3, device=DEV, train_batch=128, reg=1e-3)
+    torch.manual_seed(2)
+    m = T.LightGCN(ds, config=cfg, graph=g)
+    m.train()
+    batch = T.BPR_training_data(ds, config=cfg, seed=1).all_train_data[:128]
+    res = []
+    for restrict in (False, True):
+        m.restrict_forward = restrict
+        m.zero_grad()
+        lossx = m.loss(batch)
+        sum(lossx).backward()
+        res.append(([float(v) for v in lossx], m.table.grad.clone()))
+    (l0, g0), (l1, g1) = res
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    scale = float(g0.abs().max())
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-4, atol=1e-6 * scale)
