@@ -39,9 +39,10 @@ def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None):
     raws, invs = [], []
     x = x0
     masks = {}
-    if loss_rows is not None and n_layer >= 1 and graph.symmetric and x0.shape[1] in (8, 16, 32, 64, 128, 256):
+    if (loss_rows is not None and n_layer >= 1 and graph.symmetric and x0.shape[1] in (8, 16, 32, 64, 128, 256)
+            and loss_rows.numel() * 16 <= x0.shape[0]):              # a batch that touches most rows gains nothing
         top = torch.zeros(x0.shape[0], dtype=torch.uint8, device=x0.device)
-        top[loss_rows] = 1
+        top.index_fill_(0, loss_rows, 1)
         masks[n_layer - 1] = top
         if n_layer >= 2:
             masks[n_layer - 2] = graph.mark_rows(loss_rows, torch.zeros_like(top))
