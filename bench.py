@@ -356,8 +356,9 @@ def main():
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "mean_launch_ms": ms, "launches_timed": len(fwd),
                 "other_kernels_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items() if k != dom}}
         if args.model == "lightgcn":
-            step_bytes = 2 * L * spmm_bytes(nnz, n, D, 0) + L * n * 20 * D + 28 * n * D
-            extra["step_algorithmic_GBps"] = step_bytes / (dt / K) / 1e9 / world
+            # nominal traffic of a step that touches every row in every layer, for reference only: the
+            # timed step reads less (rows the loss does not depend on / rows whose gradient is zero are not touched)
+            extra["nominal_step_bytes_all_rows"] = 2 * L * spmm_bytes(nnz, n, D, 0) + L * n * 20 * D + 28 * n * D
         elif routed:
             extra["routing"] = {"factor_k": KF, "iterate_k": cfg["iterate_k"],
                                 "routed_products_per_step": len(fwd) // K, "score_passes_per_step": len(kernel_ms.get("route_score", [])) // K}
@@ -373,7 +374,11 @@ def main():
                "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{ {'lightgcn': 'C2', 'ngcf': 'C3'}.get(args.model, 'C2-graph') } {mname} L={L} D={D} users={nu} items={ni} "
                                       f"edges={ne} nnz={nnz} train_batch={B} adam lr=0.01 {cfg['norm_type']} {cfg['mul_loss_func']}",
-                          "train_batch": B, "parallelism": f"{parallel}-shard x{world}" if sharded else "single"},
+                          "train_batch": B, "parallelism": f"{parallel}-shard x{world}" if sharded else "single",
+                          "step": "loss -> backward -> Adam on one batch; same loss and gradients as the all-rows step: rows "
+                                  "of the top two forward layers that the batch's loss does not read are not computed, "
+                                  "backward products do not fetch operand rows that are exactly zero "
+                                  "(extra.ms_per_step_all_rows_forward = every forward layer on all rows)"},
                "roofline": roof, "extra": extra}
         if not args.no_cpu and world == 1 and args.model == "lightgcn":
             out["cpu_baseline"] = cpu_baseline(args, nnz)
