@@ -121,6 +121,10 @@ int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* rows, int64_
 int tagrec_spmm_norm_acc_rows_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
                                   float* acc, float acc_scale, const uint8_t* row_mask, float drop_p,
                                   uint64_t seed, int D, void* stream);
+/* the plain product (NGCF) and the column-sharded forward product on the rows with row_mask[r] != 0 */
+int tagrec_spmm_rows_f32(const tagrec_graph* g, const float* X, float* Y, const uint8_t* row_mask, int D, void* stream);
+int tagrec_spmm_ss_rows_f32(const tagrec_graph* g, const float* X, float* Y, float* ss, const uint8_t* row_mask, int D,
+                            void* stream);
 /* tagrec_spmm_normbwd_dot_f32 (column-sharded tables) on a row-sparse G_in */
 int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                        const unsigned* in_count, const float* X_raw, const float* inv_norm,

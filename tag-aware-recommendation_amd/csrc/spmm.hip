@@ -646,3 +646,18 @@ extern "C" int tagrec_spmm_norm_acc_rows_f32(const tagrec_graph* g, const float*
   EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr, row_mask};
   return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc_rows");
 }
+
+extern "C" int tagrec_spmm_rows_f32(const tagrec_graph* g, const float* X, float* Y, const uint8_t* row_mask, int D, void* stream) {
+  TAGREC_REQUIRE(row_mask != nullptr, "spmm_rows: null row_mask");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_rows: D must be 8 .. 256, a power of two");
+  EpiArgs e{Y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr, row_mask};
+  return launch_spmm<EPI_NONE>(g, X, e, D, stream, "spmm_rows");
+}
+
+extern "C" int tagrec_spmm_ss_rows_f32(const tagrec_graph* g, const float* X, float* Y, float* ss, const uint8_t* row_mask, int D,
+                                       void* stream) {
+  TAGREC_REQUIRE(ss != nullptr && row_mask != nullptr, "spmm_ss_rows: null ss or row_mask");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_ss_rows: D must be 8 .. 256, a power of two");
+  EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr, row_mask};
+  return launch_spmm<EPI_SS>(g, X, e, D, stream, "spmm_ss_rows");
+}

@@ -268,6 +268,13 @@ class Graph:
                                                          _lib.stream_ptr()), "graph_mark_rows")
         return flags
 
+    def spmm_rows(self, X, out, row_mask):
+        """`spmm` for the rows with row_mask[r] != 0 (the others of `out` are left as they are)."""
+        D = self._chk_x(X, self.shape[1], "spmm X")
+        self._call("spmm_rows", _lib.load().tagrec_spmm_rows_f32, self._h, _lib.ptr(X), _lib.ptr(out), _lib.ptr(row_mask), D,
+                   _lib.stream_ptr())
+        return out
+
     def spmm_norm_acc_rows(self, X, y_raw, inv_norm, acc, acc_scale, row_mask, drop_p=0.0, seed=0):
         """`spmm_norm_acc` for the rows with row_mask[r] != 0 only (the others are left as they are)."""
         D = self._chk_x(X, self.shape[1], "spmm_norm_acc X")

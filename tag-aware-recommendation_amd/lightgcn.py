@@ -33,13 +33,13 @@ def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None):
     loss_rows (int64 node ids): `out` will be read at these rows only (the batch rows of the BPR loss).  Then the last
     layer is computed on them alone and the layer below it on their neighbours (anything further down reaches nearly
     every node through the popular items, so it runs in full); the rows left out stay zero in raws / invs and are
-    never read with a non-zero gradient in the backward pass.  Needs a symmetric graph of a vector-kernel width."""
+    never read with a non-zero gradient in the backward pass.  Needs a square graph and a vector-kernel width."""
     s = 1.0 / (n_layer + 1)
     out = x0 * s
     raws, invs = [], []
     x = x0
     masks = {}
-    if (loss_rows is not None and n_layer >= 1 and graph.symmetric and x0.shape[1] in (8, 16, 32, 64, 128, 256)
+    if (loss_rows is not None and n_layer >= 1 and graph.shape[0] == graph.shape[1] and x0.shape[1] in (8, 16, 32, 64, 128, 256)
             and loss_rows.numel() * 16 <= x0.shape[0]):              # a batch that touches most rows gains nothing
         top = torch.zeros(x0.shape[0], dtype=torch.uint8, device=x0.device)
         top.index_fill_(0, loss_rows, 1)

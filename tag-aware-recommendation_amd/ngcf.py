@@ -55,15 +55,31 @@ def dense_backward(dxp, nei, x, w1p, w2p, norm=None):
     return d_nei, d_xd, dw1, dw2
 
 
-def propagate_forward(graph, x0, wps, dims):
-    """x0 [N, dims[0]] -> out [N, sum(dims)] = cat(x0, z1..zL) and the per-layer state for backward."""
+RESTRICT_FORWARD = True     # loss(): form the top two layers' neighbour sums only on the rows the batch's loss depends on
+
+
+def propagate_forward(graph, x0, wps, dims, loss_rows=None):
+    """x0 [N, dims[0]] -> out [N, sum(dims)] = cat(x0, z1..zL) and the per-layer state for backward.
+
+    loss_rows (int64 node ids): `out` will be read at these rows only (the batch rows).  Then the last layer's
+    neighbour sum is formed for them alone and the one below it for their neighbours (marked through the adjacency
+    rows; further down every row is needed); the other rows of those layers carry values that nothing reads."""
     n = x0.shape[0]
     dtot = sum(dims)
     out = torch.empty(n, dtot, dtype=torch.float32, device=x0.device)
     out[:, :dims[0]] = x0
     saved, x, off = [], x0, dims[0]
+    L = len(wps)
+    masks = {}
+    if (loss_rows is not None and L >= 1 and loss_rows.numel() * 16 <= n and graph.shape[0] == graph.shape[1]
+            and all(d in (8, 16, 32, 64, 128, 256) for d in dims[:-1])):
+        top = torch.zeros(n, dtype=torch.uint8, device=x0.device)
+        top.index_fill_(0, loss_rows, 1)
+        masks[L - 1] = top
+        if L >= 2:
+            masks[L - 2] = graph.mark_rows(loss_rows, torch.zeros_like(top))
     for k, (w1p, w2p) in enumerate(wps):
-        nei = graph.spmm(x)
+        nei = graph.spmm_rows(x, torch.zeros_like(x), masks[k]) if k in masks else graph.spmm(x)
         xp = torch.empty(n, dims[k + 1], dtype=torch.float32, device=x0.device)
         inv = torch.empty(n, dtype=torch.float32, device=x0.device)
         dense_forward(nei, x, w1p, w2p, xp, inv, out[:, off:], dtot)
@@ -132,7 +148,8 @@ class _PropagateBprLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, graph, dims, n_user, n_item, trip, loss_kind, table, *mats):
-        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims)
+        loss_rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user]) if RESTRICT_FORWARD else None
+        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims, loss_rows)
         B, dtot = trip.shape[0], out.shape[1]
         coef = torch.empty(B, dtype=torch.float32, device=out.device)
         partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=out.device)

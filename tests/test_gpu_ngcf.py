@@ -123,3 +123,34 @@ def test_unsupported_width_is_reported_not_miscomputed():
     with pytest.raises(T.TagrecError, match="128 -> 128"):
         NG.dense_forward(x, x, w, w, torch.empty(64, 128, device=DEV), torch.empty(64, device=DEV),
                          torch.empty(64, 128, device=DEV), 128)
+
+
+def test_restricted_forward_equals_full_forward_step():
+    """NGCF.loss with the top two layers' neighbour sums restricted to the rows the loss depends on vs all rows: same
+    loss parts, same gradients (table and W / b), on a graph with long rows."""
+    from tagrec_amd import ngcf as NG
+    ds = T.synth.make_bipartite_device(30_000, 20_000, 1_500_000, seed=5, device=DEV)
+    cfg = T.get_config("ngcf", use_tag=False, dim_latent=64, dim_layer_list=[64, 64, 32], device=DEV, train_batch=128, reg=1e-3)
+    e = ds.edge_index["train"]
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 30_000, 20_000, "ngcf")
+    g = T.Graph(rp, col, val, (n, n))
+    torch.manual_seed(3)
+    m = T.NGCF(ds, config=cfg, graph=g)
+    m.train()
+    batch = T.BPR_training_data(ds, config=cfg, seed=2).all_train_data[:128]
+    res = []
+    try:
+        for restrict in (False, True):
+            NG.RESTRICT_FORWARD = restrict
+            m.zero_grad()
+            lossx = m.loss(batch)
+            sum(lossx).backward()
+            res.append(([float(v) for v in lossx], {k: p.grad.clone() for k, p in m.named_parameters()}))
+    finally:
+        NG.RESTRICT_FORWARD = True
+    (l0, g0), (l1, g1) = res
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    top = max(float(v.double().norm()) for v in g0.values())
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        assert float((a - b).norm()) <= 1e-3 * float(a.norm()) + 1e-6 * top, k
