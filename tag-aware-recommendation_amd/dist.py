@@ -96,6 +96,16 @@ class HipOps:
                                                           _lib.ptr(out), x.shape[0], x.shape[1], _lib.stream_ptr()),
                    "rownorm_bwd_dot")
 
+    # -- forward restricted to the rows the batch's loss depends on (see lightgcn.propagate_forward)
+    restrict_forward = True
+
+    def mark_rows(self, g, rows, flags):
+        return g.mark_rows(rows, flags)
+
+    def spmm_ss_rows(self, g, x, y, ss, mask):
+        g._call("spmm_ss_rows", _lib.load().tagrec_spmm_ss_rows_f32, g.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(ss), _lib.ptr(mask),
+                x.shape[1], _lib.stream_ptr())
+
     # -- row-sparse gradients (the batch gradient reaches a few rows per hop; see EpiArgs::in_flags in csrc/spmm.hip)
     sparse_backward = True
 
@@ -284,10 +294,25 @@ class _FeatureShardedLoss(torch.autograd.Function):
         out = x0 * s
         raws = []
         x = x0
-        ss = torch.empty(max(L, 1), n, dtype=torch.float32, device=x0.device)
+        ss = torch.zeros(max(L, 1), n, dtype=torch.float32, device=x0.device)
+        # the loss reads `out` at the batch rows only: the top layer is formed on them, the one below on their neighbours
+        masks = {}
+        nu = m.n_user
+        if (getattr(m.ops, "restrict_forward", False) and L >= 1 and trip.shape[0] * 48 <= n
+                and x0.shape[1] in (8, 16, 32, 64, 128, 256)):
+            rows = torch.cat([trip[:, 0], trip[:, 1] + nu, trip[:, 2] + nu])
+            top = torch.zeros(n, dtype=torch.uint8, device=x0.device)
+            top.index_fill_(0, rows, 1)
+            masks[L - 1] = top
+            if L >= 2:
+                masks[L - 2] = m.ops.mark_rows(m.graph, rows, torch.zeros_like(top))
         for k in range(L):                                          # the chain A^k x0 runs on the raw products, so
-            y = torch.empty_like(x0)                                # no layer waits for a collective
-            m.ops.spmm_ss(m.graph, x, y, ss[k])
+            if k in masks:                                          # no layer waits for a collective
+                y = torch.zeros_like(x0)
+                m.ops.spmm_ss_rows(m.graph, x, y, ss[k], masks[k])
+            else:
+                y = torch.empty_like(x0)
+                m.ops.spmm_ss(m.graph, x, y, ss[k])
             raws.append(y)
             x = y
         if L:

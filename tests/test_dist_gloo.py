@@ -66,6 +66,21 @@ class CpuOps:
             dIr.index_add_(0, trip[:, 2], cr * Ir[trip[:, 2]])
 
 
+    # -- restricted forward (the toy batches touch too many rows for it to switch on; the double keeps the contract)
+    restrict_forward = True
+
+    def mark_rows(self, g, rows, flags):
+        dense = g.to_dense() != 0
+        flags[rows] = 1
+        flags[dense[rows].any(0)] = 1
+        return flags
+
+    def spmm_ss_rows(self, g, x, y, ss, mask):
+        keep = mask.bool()
+        full = g @ x
+        y[keep] = full[keep]
+        ss[keep] = (full[keep] ** 2).sum(1)
+
     # -- column-sharded tables
     def spmm_ss(self, g, x, y, ss):
         y.copy_(g @ x)
