@@ -345,7 +345,9 @@ def main():
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
         # ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction; see profiles/README.md)
         with open(pmc_path) as f:
-            traffic = json.load(f)["kernels"]["spmm_rows_kernel<16, 1>"]["traffic_bytes_per_launch"]
+            ks = json.load(f)["kernels"]
+            k = ks.get("spmm_rows_kernel<16, 1, false>") or ks.get("spmm_rows_kernel<16, 1>")
+            traffic = k["traffic_bytes_per_launch"]
     if fwd:
         ms = sum(fwd) / len(fwd)
         ach = alg / (ms * 1e-3) / 1e9

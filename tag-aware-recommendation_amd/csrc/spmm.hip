@@ -198,7 +198,9 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
 // ---- main kernel: one wave per short row; the FIRST blocks of the grid take the long-row chunks ----
 // (one wave per kChunk entries, partial sums to a slab) so the heavy items start first and the same
 // launch covers every stored entry of the matrix.
-template <int LPR, int EPI>
+// MASKED = e.row_mask given (a separate instantiation, so that profiles tell the all-rows launches from the
+// restricted ones by name)
+template <int LPR, int EPI, bool MASKED = false>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(GraphView g, const float* __restrict__ X,
                                                                             EpiArgs e, LongView lv) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
     if (c >= lv.n_chunks) return;
     const int2 d = lv.chunk_desc[c];
     const int64_t r = lv.long_rows[d.x];
-    if (e.row_mask && !e.row_mask[r]) return;
+    if (MASKED && !e.row_mask[r]) return;
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
     const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
   }
   const int64_t r = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
   if (r >= g.n_rows) return;
-  if (e.row_mask && !e.row_mask[r]) return;
+  if (MASKED && !e.row_mask[r]) return;
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
   if (end - start > kLongRow) return;  // chunked above, folded by spmm_finish_kernel
   const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_rows);
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
   row_epilogue<LPR, EPI>(acc, r, lane, e);
 }
 
-template <int LPR, int EPI>
+template <int LPR, int EPI, bool MASKED = false>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_finish_kernel(GraphView g,
                                                                               const int32_t* __restrict__ long_rows,
                                                                               const int32_t* __restrict__ long_base,
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_finish_kernel(Gra
   const int64_t li = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
   if (li >= n_long) return;
   const int64_t r = long_rows[li];
-  if (e.row_mask && !e.row_mask[r]) return;
+  if (MASKED && !e.row_mask[r]) return;
   const int64_t deg = g.rowptr[r + 1] - g.rowptr[r];
   const int nc = static_cast<int>((deg + kChunk - 1) / kChunk);
   const float4* p = reinterpret_cast<const float4*>(slab) + static_cast<int64_t>(long_base[li]) * LPR + (lane % LPR);
@@ -475,6 +477,18 @@ int launch_vec(const tagrec_graph* g, const float* X, const EpiArgs& e, hipStrea
     if (rc != TAGREC_OK) return rc;
     lv.slab = g->slab;
     lv.chunk_blocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+  }
+  if constexpr (EPI == EPI_NONE || EPI == EPI_NORM_ACC || EPI == EPI_SS) {       // the forward epilogues can be row-masked
+    if (e.row_mask) {
+      spmm_rows_kernel<LPR, EPI, true><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
+      TAGREC_LAUNCH_CHECK();
+      if (g->n_long > 0) {
+        const unsigned fblocks = static_cast<unsigned>((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+        spmm_finish_kernel<LPR, EPI, true><<<fblocks, threads, 0, s>>>(gv, g->long_rows, g->long_base, g->n_long, g->slab, e);
+        TAGREC_LAUNCH_CHECK();
+      }
+      return TAGREC_OK;
+    }
   }
   spmm_rows_kernel<LPR, EPI><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
   TAGREC_LAUNCH_CHECK();
