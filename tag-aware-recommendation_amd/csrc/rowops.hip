@@ -45,14 +45,24 @@ __global__ __launch_bounds__(kThreads) void rownorm_bwd_kernel(const float* __re
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t r = static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6);
   if (r >= n_rows) return;
+  const float* dz = dZ + r * lddz;
+  float* o = dX + r * D;
+  if (!accumulate) {
+    // the gradient is zero outside the batch rows: such a row's result is zero whatever x is, so x is not read
+    bool any_dz = false;
+    for (int k = lane; k < D; k += kWave) any_dz |= dz[k] != 0.f;
+    if (!__any(any_dz)) {
+      for (int k = lane; k < D; k += kWave) o[k] = 0.f;
+      if (row_flags && lane == 0) row_flags[r] = 0;
+      return;
+    }
+  }
   const float inv = inv_norm[r];
   const float* x = Xraw + r * D;
-  const float* dz = dZ + r * lddz;
   float dot = 0.f;
   for (int k = lane; k < D; k += kWave) dot = fmaf(x[k] * inv, dz[k] * s, dot);
   dot = wave_sum(dot);
   if (inv >= 1e12f) dot = 0.f;  // norm was clamped to eps: the denominator is a constant
-  float* o = dX + r * D;
   bool nz = false;
   for (int k = lane; k < D; k += kWave) {
     float g = inv * (dz[k] * s - x[k] * inv * dot);
