@@ -80,6 +80,18 @@ def propagate_forward(graph, x0, wps, dims, loss_rows=None):
             masks[L - 2] = graph.mark_rows(loss_rows, torch.zeros_like(top))
     for k, (w1p, w2p) in enumerate(wps):
         nei = graph.spmm_rows(x, torch.zeros_like(x), masks[k]) if k in masks else graph.spmm(x)
+        if k in masks and k == L - 1:
+            # top layer: the dense block runs on the batch rows alone (one host read: their count)
+            rows = torch.unique(loss_rows)
+            xc, nc = x.index_select(0, rows), nei.index_select(0, rows)
+            d = dims[k + 1]
+            xpc = torch.empty(rows.numel(), d, dtype=torch.float32, device=x0.device)
+            invc = torch.empty(rows.numel(), dtype=torch.float32, device=x0.device)
+            zc = torch.empty(rows.numel(), d, dtype=torch.float32, device=x0.device)
+            dense_forward(nc, xc, w1p, w2p, xpc, invc, zc, d)
+            out[:, off:off + d].index_copy_(0, rows, zc)          # the other rows of this slot are never read
+            saved.append(("rows", rows, masks[k], xc, nc, xpc, invc, w1p, w2p))
+            break
         xp = torch.empty(n, dims[k + 1], dtype=torch.float32, device=x0.device)
         inv = torch.empty(n, dtype=torch.float32, device=x0.device)
         dense_forward(nei, x, w1p, w2p, xp, inv, out[:, off:], dtot)
@@ -98,6 +110,20 @@ def propagate_backward(graph_t, d_out, saved, dims):
     dws = [None] * len(saved)
     dx_next = None
     for k in range(len(saved) - 1, -1, -1):
+        if isinstance(saved[k][0], str):                       # the top layer of a restricted forward pass: batch rows only
+            _, rows, mask, xc, nc, xpc, invc, w1p, w2p = saved[k]
+            d = dims[k + 1]
+            dzc = d_out[:, offs[k + 1]:offs[k + 1] + d].index_select(0, rows)
+            d_nei_c, d_xd_c, dw1, dw2 = dense_backward(None, nc, xc, w1p, w2p, norm=(xpc, invc, dzc, d))
+            dws[k] = (dw1, dw2)
+            din = xc.shape[1]
+            d_nei = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_copy_(0, rows, d_nei_c)
+            d_xd = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_copy_(0, rows, d_xd_c)
+            count = torch.full((1,), rows.numel(), dtype=torch.int32, device=xc.device)
+            dx = torch.empty(n, din, dtype=torch.float32, device=xc.device)
+            graph_t.spmm_axpy_sparse(d_nei, mask, count, d_xd, 1.0, dx)
+            dx_next = dx
+            continue
         x, nei, xp, inv, w1p, w2p = saved[k]
         # d Xp = (what layer k+1 sent back) + normalize-backward of this layer's concat slot, formed inside the kernel
         d_nei, d_xd, dw1, dw2 = dense_backward(dx_next, nei, x, w1p, w2p, norm=(xp, inv, d_out[:, offs[k + 1]:], dtot))
