@@ -37,6 +37,10 @@ def _edge_keys(user_items, n_item, device):
     if isinstance(user_items, dict):
         us = np.fromiter((u for u, its in user_items.items() for _ in its), dtype=np.int64)
         its = np.fromiter((i for its in user_items.values() for i in its), dtype=np.int64)
+    elif isinstance(user_items, torch.Tensor):       # [E,2] tensor, possibly already on the device
+        u = user_items[:, 0].to(device, torch.int64)
+        i = user_items[:, 1].to(device, torch.int64)
+        return u, i, torch.sort(u * n_item + i).values
     else:                                   # [E,2] array
         arr = np.asarray(user_items)
         us, its = arr[:, 0].astype(np.int64), arr[:, 1].astype(np.int64)
