@@ -359,7 +359,8 @@ def test_feature_shard_kernels_compose_to_full_width(golden, G):
     np.testing.assert_allclose(dots.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-def test_restricted_forward_equals_full_forward_step():
+@pytest.mark.parametrize("n_layer", [3, 2, 1])
+def test_restricted_forward_equals_full_forward_step(n_layer):
     """`LightGCN.loss` computes the top two layers only on the rows the batch's loss depends on (batch rows; their
     neighbours one layer down): same loss parts and the same table gradient as with every layer on all rows, on a graph
     with long rows (popular items) so that the chunked path is masked too."""
@@ -368,7 +369,8 @@ def test_restricted_forward_equals_full_forward_step():
     rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 30_000, 20_000, "bi_norm")
     g = T.Graph(rp, col, val, (n, n), symmetric=True)
     assert g.info()["n_long_rows"] > 0
-    cfg = T.get_config("lightgcn", use_tag=False, dim_latent=64, dim_layer_list=[64] * 3, device=DEV, train_batch=128, reg=1e-3)
+    cfg = T.get_config("lightgcn", use_tag=False, dim_latent=64, dim_layer_list=[64] * n_layer, device=DEV, train_batch=128,
+                       reg=1e-3)
     torch.manual_seed(2)
     m = T.LightGCN(ds, config=cfg, graph=g)
     m.train()

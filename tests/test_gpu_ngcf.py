@@ -125,12 +125,13 @@ def test_unsupported_width_is_reported_not_miscomputed():
                          torch.empty(64, 128, device=DEV), 128)
 
 
-def test_restricted_forward_equals_full_forward_step():
+@pytest.mark.parametrize("layers", [[64, 64, 32], [64, 32], [32]])
+def test_restricted_forward_equals_full_forward_step(layers):
     """NGCF.loss with the top two layers' neighbour sums restricted to the rows the loss depends on vs all rows: same
     loss parts, same gradients (table and W / b), on a graph with long rows."""
     from tagrec_amd import ngcf as NG
     ds = T.synth.make_bipartite_device(30_000, 20_000, 1_500_000, seed=5, device=DEV)
-    cfg = T.get_config("ngcf", use_tag=False, dim_latent=64, dim_layer_list=[64, 64, 32], device=DEV, train_batch=128, reg=1e-3)
+    cfg = T.get_config("ngcf", use_tag=False, dim_latent=64, dim_layer_list=layers, device=DEV, train_batch=128, reg=1e-3)
     e = ds.edge_index["train"]
     rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 30_000, 20_000, "ngcf")
     g = T.Graph(rp, col, val, (n, n))
