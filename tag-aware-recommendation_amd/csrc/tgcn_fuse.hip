@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_fwd_lds_kernel(
 #pragma unroll
       for (int i = 0; i < OS; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
     }
-    __syncthreads();     // the next group's first DMA reuses buffer 0, which the last chunk's predecessor... keep it simple
+    __syncthreads();     // every wave is done with both buffers before the next group's first DMA overwrites buffer 0
   }
 }
 
