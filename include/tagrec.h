@@ -209,6 +209,14 @@ int tagrec_route_spmm_f32(const tagrec_graph* g, const float* W, int K, const fl
                           int D, void* stream);
 int tagrec_route_score_f32(const tagrec_graph* g, const float* H, const float* T, float* logits, int K,
                            int accumulate, int D, void* stream);
+/* The same two with the restrictions of the plain products: row_mask (may be NULL) = output rows / entries' rows to
+ * compute, the others are left untouched; in_flags / in_count (may be NULL) = rows of X that hold a non-zero. */
+int tagrec_route_spmm_ex_f32(const tagrec_graph* g, const float* W, int K, const float* X, const float* post,
+                             const float* self, const float* B, float b_scale, float* Y, float* Yn, float* inv,
+                             const uint8_t* row_mask, const uint8_t* in_flags, const unsigned* in_count, int D,
+                             void* stream);
+int tagrec_route_score_rows_f32(const tagrec_graph* g, const float* H, const float* T, float* logits, int K,
+                                int accumulate, const uint8_t* row_mask, int D, void* stream);
 int tagrec_slice_scale_f32(const float* X, const float* scale, float* Y, int64_t n_rows, int D, int K, void* stream);
 int tagrec_slice_norm_fwd_f32(const float* X, float* Y, float* inv, int64_t n_rows, int D, int K, int apply_tanh,
                               void* stream);

@@ -72,6 +72,9 @@ _SIGNATURES = {
     "tagrec_route_spmm_f32": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                               c_void_p, c_int, c_void_p],
     "tagrec_route_score_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tagrec_route_spmm_ex_f32": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_route_score_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     "tagrec_slice_scale_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "tagrec_slice_norm_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     "tagrec_slice_norm_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],

@@ -46,13 +46,16 @@ struct WaveStage {
 
 template <int K>
 __device__ __forceinline__ void stage_entries(WaveStage<K>& st, const int32_t* __restrict__ col, const float* __restrict__ W,
-                                              int64_t base, int n, int lane) {
+                                              int64_t base, int n, int lane, const uint8_t* __restrict__ flags = nullptr) {
   __builtin_amdgcn_wave_barrier();          // earlier reads of the stage are done (one wave, in-order LDS)
   if (lane < n) {
-    st.col[lane] = __builtin_nontemporal_load(col + base + lane);
+    const int c = __builtin_nontemporal_load(col + base + lane);
+    st.col[lane] = c;
     if (W) {
+      // flags[c] == 0: row c of the operand is all zero -> weight 0, and entries of weight 0 are not gathered
+      const bool live = !flags || flags[c];
 #pragma unroll
-      for (int k = 0; k < K; ++k) st.w[lane * K + k] = __builtin_nontemporal_load(W + (base + lane) * K + k);
+      for (int k = 0; k < K; ++k) st.w[lane * K + k] = live ? __builtin_nontemporal_load(W + (base + lane) * K + k) : 0.f;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -63,7 +66,8 @@ __device__ __forceinline__ void stage_entries(WaveStage<K>& st, const int32_t* _
 // sum_j W[j][factor of my columns] * X[col[j], my columns] over entries [start, end).
 template <int LPR, int K>
 __device__ __forceinline__ float4 routed_gather(const GraphView& g, const float* __restrict__ W, const float* __restrict__ X,
-                                                int64_t start, int64_t end, int lane, WaveStage<K>& st) {
+                                                int64_t start, int64_t end, int lane, WaveStage<K>& st,
+                                                const uint8_t* __restrict__ flags) {
   constexpr int NPI = kWave / LPR;
   constexpr int SL = LPR / K;
   const int q = lane / LPR;
@@ -72,7 +76,7 @@ __device__ __forceinline__ float4 routed_gather(const GraphView& g, const float*
   float4 acc = r4_zero();
   for (int64_t base = start; base < end; base += kWave) {
     const int n = (end - base) < kWave ? static_cast<int>(end - base) : kWave;
-    stage_entries<K>(st, g.col, W, base, n, lane);
+    stage_entries<K>(st, g.col, W, base, n, lane, flags);
     const int groups = (n + NPI - 1) / NPI;
     for (int gi = 0; gi < groups; gi += 4) {
       float4 x[4];
@@ -80,11 +84,10 @@ __device__ __forceinline__ float4 routed_gather(const GraphView& g, const float*
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = (gi + u) * NPI + q;
-        const bool ok = j < n;
-        const int jj = ok ? j : 0;
+        const int jj = j < n ? j : 0;
         const int c = st.col[jj];
-        v[u] = ok ? st.w[jj * K + kf] : 0.f;
-        x[u] = ok ? Xv[static_cast<int64_t>(c) * LPR] : r4_zero();
+        v[u] = j < n ? st.w[jj * K + kf] : 0.f;
+        x[u] = v[u] != 0.f ? Xv[static_cast<int64_t>(c) * LPR] : r4_zero();      // a x 0 adds exactly 0: not fetched
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -109,6 +112,9 @@ struct RouteEpi {
   const float* self;    // [N, D] added to the product                 (nullable)
   const float* B;       // [N, D] added with b_scale                   (nullable)
   float b_scale;
+  const uint8_t* row_mask;   // output rows to compute (nullable = all); the others are left untouched
+  const uint8_t* in_flags;   // rows of X that hold a non-zero (nullable); consulted while *in_count < 4/5 of the rows
+  const unsigned* in_count;
 };
 
 template <int LPR, int K>
@@ -147,23 +153,26 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void route_spmm_kernel(Grap
   __shared__ WaveStage<K> stage[kWavesPerBlock];
   const int lane = threadIdx.x & (kWave - 1);
   WaveStage<K>& st = stage[threadIdx.x >> 6];
+  const uint8_t* flags = (e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_rows)) ? e.in_flags : nullptr;
   if (blockIdx.x < lv.chunk_blocks) {
     const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (c >= lv.n_chunks) return;
     const int2 d = lv.chunk_desc[c];
     const int64_t r = lv.long_rows[d.x];
+    if (e.row_mask && !e.row_mask[r]) return;
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
     const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
-    const float4 acc = routed_gather<LPR, K>(g, W, X, start, end, lane, st);
+    const float4 acc = routed_gather<LPR, K>(g, W, X, start, end, lane, st, flags);
     if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[c * LPR + lane] = acc;
     return;
   }
   const int64_t r = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
   if (r >= g.n_rows) return;
+  if (e.row_mask && !e.row_mask[r]) return;
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
   if (end - start > kLongRow) return;
-  const float4 acc = routed_gather<LPR, K>(g, W, X, start, end, lane, st);
+  const float4 acc = routed_gather<LPR, K>(g, W, X, start, end, lane, st, flags);
   route_epilogue<LPR, K>(acc, r, lane, e);
 }
 
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void route_spmm_finish_kern
   const int64_t li = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
   if (li >= n_long) return;
   const int64_t r = long_rows[li];
+  if (e.row_mask && !e.row_mask[r]) return;
   const int64_t deg = g.rowptr[r + 1] - g.rowptr[r];
   const int nc = static_cast<int>((deg + kChunk - 1) / kChunk);
   const float4* p = reinterpret_cast<const float4*>(slab) + static_cast<int64_t>(long_base[li]) * LPR + (lane % LPR);
@@ -193,7 +203,7 @@ template <int LPR, int K>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void route_score_kernel(GraphView g, const float* __restrict__ H,
                                                                               const float* __restrict__ T,
                                                                               float* __restrict__ logits, int accumulate,
-                                                                              LongView lv) {
+                                                                              LongView lv, const uint8_t* __restrict__ row_mask) {
   constexpr int NPI = kWave / LPR;
   constexpr int SL = LPR / K;
   __shared__ WaveStage<1> stage[kWavesPerBlock];
@@ -205,12 +215,14 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void route_score_kernel(Gra
     if (c >= lv.n_chunks) return;
     const int2 d = lv.chunk_desc[c];
     r = lv.long_rows[d.x];
+    if (row_mask && !row_mask[r]) return;
     start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
     end = (start + kChunk < row_end) ? start + kChunk : row_end;
   } else {
     r = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
     if (r >= g.n_rows) return;
+    if (row_mask && !row_mask[r]) return;
     start = g.rowptr[r];
     end = g.rowptr[r + 1];
     if (end - start > kLongRow) return;
@@ -508,6 +520,14 @@ extern "C" int tagrec_route_permute_f32(const float* w, const int32_t* perm, flo
 extern "C" int tagrec_route_spmm_f32(const tagrec_graph* g, const float* W, int K, const float* X, const float* post,
                                      const float* self, const float* B, float b_scale, float* Y, float* Yn, float* inv,
                                      int D, void* stream) {
+  return tagrec_route_spmm_ex_f32(g, W, K, X, post, self, B, b_scale, Y, Yn, inv, nullptr, nullptr, nullptr, D, stream);
+}
+
+extern "C" int tagrec_route_spmm_ex_f32(const tagrec_graph* g, const float* W, int K, const float* X, const float* post,
+                                        const float* self, const float* B, float b_scale, float* Y, float* Yn, float* inv,
+                                        const uint8_t* row_mask, const uint8_t* in_flags, const unsigned* in_count, int D,
+                                        void* stream) {
+  TAGREC_REQUIRE((in_flags == nullptr) == (in_count == nullptr), "route_spmm: in_flags and in_count go together");
   TAGREC_REQUIRE(g && X, "route_spmm: null graph or X");
   TAGREC_REQUIRE(g->nnz == 0 || W, "route_spmm: null weights");
   TAGREC_REQUIRE(Y || Yn, "route_spmm: no output requested");
@@ -515,7 +535,7 @@ extern "C" int tagrec_route_spmm_f32(const tagrec_graph* g, const float* W, int 
   TAGREC_REQUIRE(aligned16(X) && aligned16(Y) && aligned16(Yn) && aligned16(self) && aligned16(B), "route_spmm: rows must be 16-byte aligned");
   if (g->n_rows == 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const RouteEpi e{Y, Yn, inv, post, self, B, b_scale};
+  const RouteEpi e{Y, Yn, inv, post, self, B, b_scale, row_mask, in_flags, in_count};
   return route_dispatch(D, K, "route_spmm", [&](auto lc, auto kc) {
     constexpr int LPR = decltype(lc)::value, KK = decltype(kc)::value;
     LongView lv;
@@ -536,6 +556,11 @@ extern "C" int tagrec_route_spmm_f32(const tagrec_graph* g, const float* W, int 
 
 extern "C" int tagrec_route_score_f32(const tagrec_graph* g, const float* H, const float* T, float* logits, int K,
                                       int accumulate, int D, void* stream) {
+  return tagrec_route_score_rows_f32(g, H, T, logits, K, accumulate, nullptr, D, stream);
+}
+
+extern "C" int tagrec_route_score_rows_f32(const tagrec_graph* g, const float* H, const float* T, float* logits, int K,
+                                           int accumulate, const uint8_t* row_mask, int D, void* stream) {
   TAGREC_REQUIRE(g && H && T, "route_score: null pointer");
   TAGREC_REQUIRE(g->nnz == 0 || logits, "route_score: null logits");
   TAGREC_REQUIRE(aligned16(H) && aligned16(T), "route_score: rows must be 16-byte aligned");
@@ -547,7 +572,7 @@ extern "C" int tagrec_route_score_f32(const tagrec_graph* g, const float* H, con
                 g->n_long > 0 ? static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock) : 0u};
     const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
     const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
-    route_score_kernel<LPR, KK><<<blocks + lv.chunk_blocks, kWavesPerBlock * kWave, 0, s>>>(gv, H, T, logits, accumulate, lv);
+    route_score_kernel<LPR, KK><<<blocks + lv.chunk_blocks, kWavesPerBlock * kWave, 0, s>>>(gv, H, T, logits, accumulate, lv, row_mask);
     TAGREC_LAUNCH_CHECK();
     return TAGREC_OK;
   });

@@ -25,17 +25,22 @@ class _RoutedLayer(torch.autograd.Function):
     `logits` ([nnz, K], the reference's A_values) is updated in place; `keep` collects the last iteration's weights."""
 
     @staticmethod
-    def forward(ctx, ego, rg, logits, iterate_k, update_last, keep):
+    def forward(ctx, ego, rg, logits, iterate_k, update_last, keep, row_masks=None):
+        """row_masks (top layer of a loss; one uint8 [n] mask or None per routing iteration): the rows whose product and
+        scores that iteration must form.  The last iteration's output is read at the batch rows only; the iteration
+        before it must be right on their neighbours too (a row's output uses the neighbours' row sums, which come from
+        the neighbours' own scores of the previous iteration); earlier ones run in full."""
         ego = ego.detach().contiguous()
         K = logits.shape[1]
         t_emb, _ = R.slice_norm_fwd(ego, K, tanh=True, want_inv=False)        # tanh(normalize(ego_split[tail])), :107-108
         for t in range(iterate_k):
+            row_mask = row_masks[t] if row_masks is not None else None
             w = rg.softmax(logits)                                            # :75
             d = rg.rowsum_rsqrt(w)                                            # :95-99
             xs = R.slice_scale(ego, d)                                        # D x           (:101)
-            f, h, inv = rg.spmm(w, xs, post=d, raw=True, normed=True)         # D A D x       (:102-103), normalize (:106)
+            f, h, inv = rg.spmm(w, xs, post=d, raw=True, normed=True, row_mask=row_mask)   # D A D x (:102-103), normalize (:106)
             if t < iterate_k - 1 or update_last:
-                rg.score(h, t_emb, logits, accumulate=True)                   # A_values += A_score (:84-85)
+                rg.score(h, t_emb, logits, accumulate=True, row_mask=row_mask)   # A_values += A_score (:84-85)
         if keep is not None:
             keep.append(w)
         ctx.rg = rg
@@ -47,8 +52,9 @@ class _RoutedLayer(torch.autograd.Function):
         f, inv, d, w = ctx.saved_tensors
         rg = ctx.rg
         df = R.slice_norm_bwd(f, inv, g.contiguous())                         # through F.normalize (:87)
-        dx, _, _ = rg.spmm(w, R.slice_scale(df, d), post=d, transposed=True)   # (D A D)^T = D A^T D
-        return dx, None, None, None, None, None
+        # (D A D)^T = D A^T D; df is non-zero only on the rows the batch gradient has reached
+        dx, _, _ = rg.spmm(w, R.slice_scale(df, d), post=d, transposed=True, sparse_x=True)
+        return dx, None, None, None, None, None, None
 
 
 class DGCF(TableModel):
@@ -71,8 +77,11 @@ class DGCF(TableModel):
         self.cor_reg = config.get("cor_reg", 0)
         self.loss_func = config["mul_loss_func"]
         self.use_tag = config["use_tag"]
+        self.restrict_forward = bool(config.get("restrict_forward", True))
 
-    def forward(self, out_A=False):
+    def forward(self, out_A=False, loss_rows=None):
+        """loss_rows (node ids): the caller reads the result at these rows only (`loss`); the top layer is then
+        computed on them alone."""
         rg = self.routing
         logits = torch.ones(rg.nnz, self.factor_k, dtype=torch.float32, device=self.device)    # A_values (:52)
         ego = self.table
@@ -80,7 +89,15 @@ class DGCF(TableModel):
         keep = [] if out_A else None
         for k in range(self.num_layer):
             last = k == self.num_layer - 1
-            ego = _RoutedLayer.apply(ego, rg, logits, self.iterate_k, not last, keep)
+            masks = None
+            if last and not out_A:
+                top = rg.loss_row_mask(loss_rows)
+                if top is not None:
+                    masks = [None] * self.iterate_k
+                    masks[-1] = top
+                    if self.iterate_k >= 2:
+                        masks[-2] = self.norm_adj.mark_rows(loss_rows, torch.zeros_like(top))
+            ego = _RoutedLayer.apply(ego, rg, logits, self.iterate_k, not last, keep, masks)
             layers.append(ego)
         if out_A:
             idx = torch.stack([rg.rows, rg.cols])
@@ -92,7 +109,9 @@ class DGCF(TableModel):
     def loss(self, batch_data):
         data = batch_data[0] if isinstance(batch_data, (tuple, list)) else batch_data       # (triplets, cor), :116
         data = data.to(self.device, torch.int64).contiguous()
-        all_users, all_items = self.forward()[:2]
+        nu = self.num_list[0]
+        rows = torch.cat([data[:, 0], data[:, 1] + nu, data[:, 2] + nu]) if self.restrict_forward else None
+        all_users, all_items = self.forward(loss_rows=rows)[:2]
         ego = self.embed
         loss, reg_loss = H.triplet_loss(all_users, all_items, ego[0], ego[1], data, self.loss_func)
         return loss, self.reg * reg_loss

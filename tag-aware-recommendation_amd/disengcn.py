@@ -23,14 +23,16 @@ class _Route(torch.autograd.Function):
     """f [n, D] (per-slice normalised) -> new_f after `iterate_k` routing rounds (disengcn.py:29-44)."""
 
     @staticmethod
-    def forward(ctx, f, rg, K, iterate_k):
+    def forward(ctx, f, rg, K, iterate_k, row_mask=None):
+        """row_mask (last layer of a loss): only these rows of the result are read, so every routing round scores and
+        aggregates their entries alone (a row's rounds depend on its own earlier rounds and on f, not on other rows')."""
         f = f.detach().contiguous()
-        logits = torch.empty(rg.nnz, K, dtype=torch.float32, device=f.device)
+        logits = (torch.zeros if row_mask is not None else torch.empty)(rg.nnz, K, dtype=torch.float32, device=f.device)
         new_f = f
         for _ in range(iterate_k):
-            rg.score(new_f, f, logits, accumulate=False)                      # <head, tail> per factor (:31-33)
+            rg.score(new_f, f, logits, accumulate=False, row_mask=row_mask)   # <head, tail> per factor (:31-33)
             w = rg.softmax(logits)                                            # :34
-            raw, new_f, inv = rg.spmm(w, f, self_add=f, raw=True, normed=True)  # f + A(p) f, normalize (:40-42)
+            raw, new_f, inv = rg.spmm(w, f, self_add=f, raw=True, normed=True, row_mask=row_mask)   # f + A(p) f, normalize (:40-42)
         ctx.rg = rg
         ctx.save_for_backward(raw, inv, w)
         return new_f
@@ -40,8 +42,8 @@ class _Route(torch.autograd.Function):
         raw, inv, w = ctx.saved_tensors
         rg = ctx.rg
         draw = R.slice_norm_bwd(raw, inv, g.contiguous())
-        df, _, _ = rg.spmm(w, draw, self_add=draw, transposed=True)
-        return df, None, None, None
+        df, _, _ = rg.spmm(w, draw, self_add=draw, transposed=True, sparse_x=True)
+        return df, None, None, None, None
 
 
 class Layer(nn.Module):
@@ -52,12 +54,12 @@ class Layer(nn.Module):
         self.W = nn.Parameter(torch.empty(fac_k, in_dim, dim_k))
         self.b = nn.Parameter(torch.empty(fac_k, 1, dim_k))
 
-    def forward(self, rg, all_emb):
+    def forward(self, rg, all_emb, row_mask=None):
         # K projections x (W_k + b_k) as one GEMM: column block k of the [in, out] matrix is W_k + b_k (:24)
         wb = (self.W + self.b).permute(1, 0, 2).reshape(self.in_dim, self.out_dim)
         f = torch.nn.functional.leaky_relu(torch.matmul(all_emb, wb), 0.2)
         f = R.slice_normalize(f, self.fac_k)
-        return _Route.apply(f, rg, self.fac_k, self.iter_k)
+        return _Route.apply(f, rg, self.fac_k, self.iter_k, row_mask)
 
 
 class DisenGCN(TableModel):
@@ -88,17 +90,23 @@ class DisenGCN(TableModel):
         self.loss_func = config["mul_loss_func"]
         self.use_tag = config["use_tag"]
         self.message_drop_list = config["message_drop_list"]
+        self.restrict_forward = bool(config.get("restrict_forward", True))
 
-    def forward(self):
+    def forward(self, loss_rows=None):
+        """loss_rows (node ids): the caller reads the result at these rows only (`loss`): the last layer's routing
+        then runs on them alone."""
         x = self.table
         for i, lyr in enumerate(self.layer):
-            x = lyr(self.routing, x)
+            mask = self.routing.loss_row_mask(loss_rows) if i == len(self.layer) - 1 else None
+            x = lyr(self.routing, x, mask)
             x = torch.nn.functional.dropout(x, p=self.message_drop_list[i], training=self.training)
         return self._split(x)
 
     def loss(self, batch_data):
         data = batch_data[0] if isinstance(batch_data, (tuple, list)) else batch_data
         data = data.to(self.device, torch.int64).contiguous()
-        all_users, all_items = self.forward()[:2]
+        nu = self.num_list[0]
+        rows = torch.cat([data[:, 0], data[:, 1] + nu, data[:, 2] + nu]) if self.restrict_forward else None
+        all_users, all_items = self.forward(loss_rows=rows)[:2]
         loss, reg_loss = H.triplet_loss(all_users, all_items, all_users, all_items, data, self.loss_func)
         return loss, self.reg * reg_loss

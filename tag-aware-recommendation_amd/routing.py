@@ -68,26 +68,45 @@ class RoutingGraph:
                                                         _lib.stream_ptr()), "route_permute")
         return wt
 
-    def spmm(self, w, x, post=None, self_add=None, b=None, b_scale=0.0, raw=True, normed=False, transposed=False):
+    def spmm(self, w, x, post=None, self_add=None, b=None, b_scale=0.0, raw=True, normed=False, transposed=False,
+             row_mask=None, sparse_x=False):
         """(Y, Yn, inv): y = post * (A(w) x) + self_add + b_scale * b;  Yn / inv = per-slice L2 normalisation of y.
-        transposed=True: A(w)^T x (w in the ORIGINAL entry order; it is permuted here)."""
+        transposed=True: A(w)^T x (w in the ORIGINAL entry order; it is permuted here).
+        row_mask (uint8 [n]): only the rows with a non-zero byte are computed; the others come back as zeros.
+        sparse_x: x is expected to have many all-zero rows (a gradient a few hops from the batch rows): they are
+        flagged first and not gathered (same result)."""
         _lib.require_gpu_tensor(x, torch.float32, "route_spmm x")
         g = self.graph
         if transposed:
             g, w = self.graph_t, self.permute(w)
         K, D = w.shape[1], x.shape[1]
         n_out = g.shape[0]
-        y = torch.empty(n_out, D, dtype=torch.float32, device=self.device) if raw else None
-        yn = torch.empty(n_out, D, dtype=torch.float32, device=self.device) if normed else None
-        inv = torch.empty(n_out, K, dtype=torch.float32, device=self.device) if normed else None
-        self.graph._call("route_spmm", _lib.load().tagrec_route_spmm_f32, g.handle, _lib.ptr(w), K, _lib.ptr(x),
+        new = torch.zeros if row_mask is not None else torch.empty
+        y = new(n_out, D, dtype=torch.float32, device=self.device) if raw else None
+        yn = new(n_out, D, dtype=torch.float32, device=self.device) if normed else None
+        inv = new(n_out, K, dtype=torch.float32, device=self.device) if normed else None
+        flags = count = None
+        if sparse_x:
+            flags = torch.empty(x.shape[0], dtype=torch.uint8, device=self.device)
+            count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            _lib.check(_lib.load().tagrec_row_flags_f32(_lib.ptr(x), x.shape[0], D, _lib.ptr(flags), _lib.ptr(count),
+                                                        _lib.stream_ptr()), "row_flags")
+        self.graph._call("route_spmm", _lib.load().tagrec_route_spmm_ex_f32, g.handle, _lib.ptr(w), K, _lib.ptr(x),
                          _lib.ptr(post), _lib.ptr(self_add), _lib.ptr(b), float(b_scale), _lib.ptr(y), _lib.ptr(yn),
-                         _lib.ptr(inv), D, _lib.stream_ptr())
+                         _lib.ptr(inv), _lib.ptr(row_mask), _lib.ptr(flags), _lib.ptr(count), D, _lib.stream_ptr())
         return y, yn, inv
 
-    def score(self, h, t, logits, accumulate):
-        self.graph._call("route_score", _lib.load().tagrec_route_score_f32, self.graph.handle, _lib.ptr(h), _lib.ptr(t),
-                         _lib.ptr(logits), logits.shape[1], int(bool(accumulate)), h.shape[1], _lib.stream_ptr())
+    def score(self, h, t, logits, accumulate, row_mask=None):
+        """row_mask: only the entries of rows with a non-zero byte are scored (the others keep their logits)."""
+        self.graph._call("route_score", _lib.load().tagrec_route_score_rows_f32, self.graph.handle, _lib.ptr(h), _lib.ptr(t),
+                         _lib.ptr(logits), logits.shape[1], int(bool(accumulate)), _lib.ptr(row_mask), h.shape[1],
+                         _lib.stream_ptr())
+
+    def loss_row_mask(self, loss_rows):
+        """uint8 [n] mask of the rows a loss reads, or None when they are too many for a restriction to pay."""
+        if loss_rows is None or loss_rows.numel() * 16 > self.n:
+            return None
+        return torch.zeros(self.n, dtype=torch.uint8, device=self.device).index_fill_(0, loss_rows, 1)
 
 
     def row_softmax(self, logits):

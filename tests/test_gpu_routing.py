@@ -438,3 +438,29 @@ def test_kgat_training_data_producer(golden):
     # relation ids follow create_edge's keys; heads / tails its rows
     e0 = data.create_edge()[0]
     assert np.array_equal(prod.all_triplet[:e0.shape[1]].cpu().numpy(), np.stack([e0[0], np.zeros_like(e0[0]), e0[1]], 1))
+
+
+@pytest.mark.parametrize("name", ["dgcf", "disengcn"])
+def test_restricted_top_layer_equals_full_step(name):
+    """DGCF / DisenGCN `loss` with the top layer's routing restricted to the rows the loss depends on, and the backward
+    products skipping zero gradient rows, vs everything on all rows: same loss parts, same gradients."""
+    ds = T.synth.make_cf_dataset(9000, 7000, 150_000, seed=13, n_tag=2000, n_assign=60_000)
+    cfg = T.get_config(name, use_tag=True, dim_layer_list=[64, 64], dim_latent=64, reg=1e-3, factor_k=4, iterate_k=2, device=DEV,
+                       train_batch=128)
+    torch.manual_seed(6)
+    m = {"dgcf": T.DGCF, "disengcn": T.DisenGCN}[name](ds, config=cfg)
+    m.train()
+    batch = torch.from_numpy(T.synth.sample_bpr_epoch(ds, 1)[:128]).to(DEV)
+    res = []
+    for restrict in (False, True):
+        m.restrict_forward = restrict
+        m.zero_grad()
+        lossx = m.loss(batch)
+        sum(lossx).backward()
+        res.append(([float(v) for v in lossx], {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (l0, g0), (l1, g1) = res
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    top = max(float(v.double().norm()) for v in g0.values())
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        assert float((a - b).norm()) <= 1e-3 * float(a.norm()) + 1e-6 * top, k
