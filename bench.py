@@ -334,9 +334,9 @@ def main():
     if routed:
         # routed product: per stored entry col + K weights + one D-wide row; per row rowptr + the outputs it writes
         # (forward: raw + normalised + K inverse norms; backward: one); mean over the launches of a step
-        n_fwd, n_bwd = L * cfg["iterate_k"], L
-        per_row = (n_fwd * (8 + 8 * D + 8 * KF + (4 * D if args.model == "disengcn" else 0)) +
-                   n_bwd * (8 + 4 * D + (4 * D if args.model == "disengcn" else 4 * KF))) / (n_fwd + n_bwd)
+        # (the all-rows forward launches; the top layer's restricted launches and the row-sparse backward ones are
+        # timed under their own key)
+        per_row = 8 + 8 * D + 8 * KF + (4 * D if args.model == "disengcn" else 0)
         alg = local_nnz * (4 + 4 * KF + 4 * D) + n_local_rows * per_row
     roof = None
     traffic = None

@@ -91,14 +91,16 @@ class RoutingGraph:
             count = torch.zeros(1, dtype=torch.int32, device=self.device)
             _lib.check(_lib.load().tagrec_row_flags_f32(_lib.ptr(x), x.shape[0], D, _lib.ptr(flags), _lib.ptr(count),
                                                         _lib.stream_ptr()), "row_flags")
-        self.graph._call("route_spmm", _lib.load().tagrec_route_spmm_ex_f32, g.handle, _lib.ptr(w), K, _lib.ptr(x),
+        name = "route_spmm" if (row_mask is None and not sparse_x) else "route_spmm_restricted"     # timing key
+        self.graph._call(name, _lib.load().tagrec_route_spmm_ex_f32, g.handle, _lib.ptr(w), K, _lib.ptr(x),
                          _lib.ptr(post), _lib.ptr(self_add), _lib.ptr(b), float(b_scale), _lib.ptr(y), _lib.ptr(yn),
                          _lib.ptr(inv), _lib.ptr(row_mask), _lib.ptr(flags), _lib.ptr(count), D, _lib.stream_ptr())
         return y, yn, inv
 
     def score(self, h, t, logits, accumulate, row_mask=None):
         """row_mask: only the entries of rows with a non-zero byte are scored (the others keep their logits)."""
-        self.graph._call("route_score", _lib.load().tagrec_route_score_rows_f32, self.graph.handle, _lib.ptr(h), _lib.ptr(t),
+        self.graph._call("route_score" if row_mask is None else "route_score_rows", _lib.load().tagrec_route_score_rows_f32,
+                         self.graph.handle, _lib.ptr(h), _lib.ptr(t),
                          _lib.ptr(logits), logits.shape[1], int(bool(accumulate)), _lib.ptr(row_mask), h.shape[1],
                          _lib.stream_ptr())
 
