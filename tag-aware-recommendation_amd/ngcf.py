@@ -80,7 +80,7 @@ def propagate_forward(graph, x0, wps, dims, loss_rows=None):
             masks[L - 2] = graph.mark_rows(loss_rows, torch.zeros_like(top))
     for k, (w1p, w2p) in enumerate(wps):
         nei = graph.spmm_rows(x, torch.zeros_like(x), masks[k]) if k in masks else graph.spmm(x)
-        if k in masks and k == L - 1:
+        if k in masks and k == L - 1 and not torch.cuda.is_current_stream_capturing():      # (needs a host read)
             # top layer: the dense block runs on the batch rows alone (one host read: their count)
             rows = torch.unique(loss_rows)
             xc, nc = x.index_select(0, rows), nei.index_select(0, rows)

@@ -83,7 +83,7 @@ class _NbrAttention(torch.autograd.Function):
         inv = ctx.inv
         # Row-local in d_out like the dense block: nodes whose output gradient is zero (all but the batch rows / their
         # sampled neighbours) are dropped, and the few remaining (node, neighbour) pairs use the scatter form.
-        if n >= _SPARSE_MIN_ROWS:
+        if n >= _SPARSE_MIN_ROWS and not torch.cuda.is_current_stream_capturing():      # (needs a host read)
             active = torch.nonzero(d_out.abs().amax(dim=1) > 0).flatten()
             if active.numel() * 2 < n:
                 dPc = torch.empty(active.numel(), A, dtype=torch.float32, device=P.device)
@@ -196,7 +196,7 @@ class _FusedDense(torch.autograd.Function):
         # sampled neighbours one layer down, so the rows with d_out[r] == 0 are dropped before the kernels run (exact:
         # they contribute 0) and the results scattered back.  One host read of the row count per call.
         active = None
-        if n >= _SPARSE_MIN_ROWS:
+        if n >= _SPARSE_MIN_ROWS and not torch.cuda.is_current_stream_capturing():      # (needs a host read)
             nz = torch.nonzero(d_out.abs().amax(dim=1) > 0).flatten()
             if nz.numel() * 2 < n:
                 active = nz
@@ -592,7 +592,7 @@ class TGCN(nn.Module):
 
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
-        if self.prune_forward and self.training:
+        if self.prune_forward and self.training and not torch.cuda.is_current_stream_capturing():
             all_users, all_items = self._forward_rows(batch_data)
         else:
             all_users, all_items = self.forward()[:2]
