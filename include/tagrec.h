@@ -52,6 +52,11 @@ int tagrec_device_info(int* n_cu, int* wave_size, char* arch, int arch_len);
  * reduced in a fixed order, so results do not depend on scheduling. */
 int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz,
                         const int64_t* rowptr, const int32_t* colidx, const float* vals, void* stream);
+/* A second matrix over the SAME row pointer (same rows, same entries per row) with its own column indices / values,
+ * e.g. the two inverted neighbour tables of the TGCN attention backward: shares `like`'s long-row work list instead of
+ * scanning again (no synchronisation).  `like` must outlive the new handle. */
+int tagrec_graph_create_like(tagrec_graph** out, const tagrec_graph* like, int64_t n_cols, const int32_t* colidx,
+                             const float* vals);
 int tagrec_graph_destroy(tagrec_graph* g);
 int tagrec_graph_info(const tagrec_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
                       int64_t* n_long_rows, int64_t* n_chunks);

@@ -16,6 +16,7 @@ struct tagrec_graph {
   int2* chunk_desc;
   mutable float* slab;        // n_chunks x D partial sums, grown on demand
   mutable size_t slab_floats;
+  bool owns_long;             // false: long_rows / long_base / chunk_desc belong to the graph this one was created like
 };
 
 namespace tagrec {

@@ -397,7 +397,7 @@ extern "C" int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n
   hipStream_t s = static_cast<hipStream_t>(stream);
   tagrec_graph* g = new (std::nothrow) tagrec_graph();
   if (!g) return fail(TAGREC_E_NOMEM, "graph_create: host allocation failed");
-  *g = tagrec_graph{n_rows, n_cols, nnz, rowptr, colidx, vals, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  *g = tagrec_graph{n_rows, n_cols, nnz, rowptr, colidx, vals, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, true};
   if (n_rows > 0) {
     unsigned long long* counters = nullptr;
     unsigned long long host[4] = {0, 0, 0, 0};
@@ -432,11 +432,30 @@ extern "C" int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n
   return TAGREC_OK;
 }
 
+extern "C" int tagrec_graph_create_like(tagrec_graph** out, const tagrec_graph* like, int64_t n_cols, const int32_t* colidx,
+                                        const float* vals) {
+  TAGREC_REQUIRE(out != nullptr && like != nullptr, "graph_create_like: null handle");
+  TAGREC_REQUIRE(n_cols >= 0 && n_cols < (1ll << 31), "graph_create_like: node ids must fit int32");
+  TAGREC_REQUIRE(like->nnz == 0 || (colidx != nullptr && vals != nullptr), "graph_create_like: colidx/vals null with nnz > 0");
+  tagrec_graph* g = new (std::nothrow) tagrec_graph(*like);
+  if (!g) return fail(TAGREC_E_NOMEM, "graph_create_like: host allocation failed");
+  g->n_cols = n_cols;
+  g->col = colidx;
+  g->val = vals;
+  g->slab = nullptr;
+  g->slab_floats = 0;
+  g->owns_long = false;
+  *out = g;
+  return TAGREC_OK;
+}
+
 extern "C" int tagrec_graph_destroy(tagrec_graph* g) {
   if (!g) return TAGREC_OK;
-  (void)hipFree(g->long_rows);
-  (void)hipFree(g->long_base);
-  (void)hipFree(g->chunk_desc);
+  if (g->owns_long) {
+    (void)hipFree(g->long_rows);
+    (void)hipFree(g->long_base);
+    (void)hipFree(g->chunk_desc);
+  }
   (void)hipFree(g->slab);
   delete g;
   return TAGREC_OK;

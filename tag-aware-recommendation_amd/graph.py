@@ -169,6 +169,22 @@ class Graph:
                                                _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()),
                        "graph_create")
 
+    def like(self, col, val, n_cols):
+        """A second matrix over this graph's row pointer with its own columns / values; shares the long-row work list
+        (no second scan, no synchronisation).  Keeps `self` alive."""
+        g = object.__new__(Graph)
+        g.rowptr = self.rowptr
+        g.col = _lib.require_gpu_tensor(col, torch.int32, "col")
+        g.val = _lib.require_gpu_tensor(val, torch.float32, "val")
+        if col.numel() != self.col.numel() or val.numel() != col.numel():
+            raise _lib.TagrecError("Graph.like: needs as many stored entries as the graph it is made like")
+        g.shape = (self.shape[0], int(n_cols))
+        g.symmetric, g._T, g.timing, g._parent = False, None, None, self
+        g._h = _lib.c_void_p()
+        _lib.check(_lib.load().tagrec_graph_create_like(_lib.ctypes.byref(g._h), self._h, g.shape[1], _lib.ptr(col),
+                                                        _lib.ptr(val)), "graph_create_like")
+        return g
+
     @classmethod
     def from_host(cls, rowptr, col, val, shape, device, symmetric=False):
         dev = torch.device(device)

@@ -52,6 +52,20 @@ class InverseTable:
                        (n_dst, n))
 
 
+def _pull_compact(idxc, attnc, doc, dh, n_dst):
+    """dQ = S dh and dEj = G dOut for a COMPACT set of source rows (`InverseTable` built on the spot: one radix sort of
+    the rows' n k neighbour ids; pad slots sort behind the last destination row and are never read)."""
+    nc, k = idxc.shape
+    flat = idxc.flatten()
+    key = torch.where(flat > 0, flat - 1, n_dst)
+    skey, order = torch.sort(key, stable=True)
+    rowptr = torch.searchsorted(skey, torch.arange(n_dst + 1, dtype=skey.dtype, device=skey.device))
+    G = Graph(rowptr, torch.div(order, k, rounding_mode="floor").to(torch.int32), attnc.flatten().index_select(0, order),
+              (n_dst, nc))
+    S = G.like(order.to(torch.int32), torch.ones_like(G.val), nc * k)
+    return S.spmm(dh), G.spmm(doc)
+
+
 class _NbrAttention(torch.autograd.Function):
     """(P, Q, WT, v, Ej) + static index tables -> attended neighbour embedding [n, D]."""
 
@@ -86,20 +100,30 @@ class _NbrAttention(torch.autograd.Function):
         if n >= _SPARSE_MIN_ROWS and not torch.cuda.is_current_stream_capturing():      # (needs a host read)
             active = torch.nonzero(d_out.abs().amax(dim=1) > 0).flatten()
             if active.numel() * 2 < n:
-                dPc = torch.empty(active.numel(), A, dtype=torch.float32, device=P.device)
-                dQ, dEj = torch.zeros_like(Q), torch.zeros_like(Ej)
-                if active.numel() > 0:
+                nc = active.numel()
+                dPc = torch.empty(nc, A, dtype=torch.float32, device=P.device)
+                pull = nc >= _PULL_MIN_ROWS
+                if pull:                 # dh for the active rows; dQ / dEj pulled over a table inverted on the spot
+                    dQ = dEj = None
+                    dh = torch.empty(nc * k, A, dtype=torch.float32, device=P.device)
+                else:                    # a few thousand (node, neighbour) pairs: float atomics into zeroed buffers
+                    dQ, dEj, dh = torch.zeros_like(Q), torch.zeros_like(Ej), None
+                if nc > 0:
                     sel = lambda x: x.index_select(0, active)
                     Pc, idxc, widxc, attnc, doc = sel(P), sel(idx), sel(widx), sel(attn), sel(d_out)
                     _lib.check(_timed("attn_bwd", lib.tagrec_tgcn_attn_bwd_f32, _lib.ptr(Pc), _lib.ptr(Q), _lib.ptr(WT),
                                       _lib.ptr(v), _lib.ptr(Ej), _lib.ptr(idxc), _lib.ptr(widxc), _lib.ptr(attnc), _lib.ptr(doc),
-                                      active.numel(), k, D, A, n_wt, _lib.ptr(dPc), _lib.ptr(dQ), _lib.ptr(dEj), None,
+                                      nc, k, D, A, n_wt, _lib.ptr(dPc), _lib.ptr(dQ), _lib.ptr(dEj), _lib.ptr(dh),
                                       _lib.ptr(dWT), _lib.ptr(dv), _lib.ptr(ws), ws_n, _lib.stream_ptr()), "tgcn_attn_bwd")
+                    if pull:
+                        dQ, dEj = _pull_compact(idxc, attnc, doc, dh, Ej.shape[0])
                 else:
                     dWT.zero_(); dv.zero_()
                 dP = torch.zeros_like(P).index_copy_(0, active, dPc)
                 return dP, dQ, dWT, dv, dEj, None, None, None
-        if inv is None:                  # scatter form: float atomics into zeroed buffers
+        # a row subset of the pruned forward arrives without a prebuilt table: invert its rows on the spot
+        spot = inv is None and n >= _PULL_MIN_ROWS and not torch.cuda.is_current_stream_capturing()
+        if inv is None and not spot:     # scatter form: float atomics into zeroed buffers
             dQ, dEj, dh = torch.zeros_like(Q), torch.zeros_like(Ej), None
         else:                            # pull form: write dh, finish with two SpMMs over the inverted table
             dQ = dEj = None
@@ -112,6 +136,8 @@ class _NbrAttention(torch.autograd.Function):
             torch.index_select(attn.reshape(-1), 0, inv.perm, out=inv.G.val)
             dEj = inv.G.spmm(d_out)
             dQ = inv.S.spmm(dh)
+        elif spot:
+            dQ, dEj = _pull_compact(idx, attn, d_out, dh, Ej.shape[0])
         return dP, dQ, dWT, dv, dEj, None, None, None
 
 
@@ -425,6 +451,7 @@ def neighbor_tables_device(rel, neighbor_k, seed=0):
 
 
 timing = None     # set to {} to record (start, end) events around the attention kernels (bench.py)
+_PULL_MIN_ROWS = 8192          # compact attention backward: pull form from this many active rows on
 _SPARSE_MIN_ROWS = 16384      # below this a backward call is too small for dropping its zero-gradient rows to pay
 
 

@@ -282,8 +282,9 @@ def test_fused_dense_backward_drops_zero_gradient_rows():
 
 
 def test_attention_backward_drops_zero_gradient_rows():
-    """`_NbrAttention.backward` on a gradient that is non-zero for a few nodes only: the compacted scatter-form pass
-    gives the gradients of the all-rows pass (pull form through the inverted table)."""
+    """`_NbrAttention.backward` on a gradient that is non-zero for a few nodes only: the compacted passes (scatter
+    form for a handful of rows, pull form over a table inverted on the spot for more) give the gradients of the
+    all-rows pass (pull form through the prebuilt inverted table)."""
     from tagrec_amd import tgcn as TG
     n, n_nbr, k, D, A, n_wt = 4000, 3000, 7, 64, 32, 9
     gen = torch.Generator(device="cpu").manual_seed(11)
@@ -297,16 +298,18 @@ def test_attention_backward_drops_zero_gradient_rows():
     d_out[rows] = rnd(61, D)
     inv = TG.InverseTable(idx32, n_nbr)
     grads = []
-    old = TG._SPARSE_MIN_ROWS
+    old, old_pull = TG._SPARSE_MIN_ROWS, TG._PULL_MIN_ROWS
     try:
-        for thr, use_inv in ((10 ** 9, inv), (0, inv), (0, None)):
-            TG._SPARSE_MIN_ROWS = thr
+        # all rows (pull form, prebuilt table); compact scatter form; compact pull form (table inverted on the spot)
+        for thr, pull, use_inv in ((10 ** 9, 10 ** 9, inv), (0, 10 ** 9, inv), (0, 10 ** 9, None), (0, 0, None),
+                                   (10 ** 9, 0, None)):             # last: all rows of a subset call, no prebuilt table
+            TG._SPARSE_MIN_ROWS, TG._PULL_MIN_ROWS = thr, pull
             xs = [b.clone().requires_grad_() for b in base]
             out = TG.neighbour_attention(xs[0], xs[1], xs[2], xs[3], xs[4], idx32, widx32, use_inv)
             out.backward(d_out)
             grads.append([x.grad.clone() for x in xs])
     finally:
-        TG._SPARSE_MIN_ROWS = old
+        TG._SPARSE_MIN_ROWS, TG._PULL_MIN_ROWS = old, old_pull
     for other in grads[1:]:
         for a, b in zip(grads[0], other):
             scale = float(a.abs().max()) + 1e-30
@@ -384,3 +387,34 @@ def test_pruned_and_row_sparse_step_equals_full_step_at_mid_scale():
     for k in g0:
         a, b = g0[k].double(), g1[k].double()
         assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 2e-6 * top, k
+
+
+def test_compact_pull_backward_with_a_popular_neighbour():
+    """The on-the-spot inverted table of the compact attention backward when one destination row collects more than
+    1024 (node, slot) pairs (a long row of the SpMM kernel) and pads are present: dQ / dEj equal the scatter form's."""
+    from tagrec_amd import tgcn as TG
+    n, n_nbr, k, D, A, n_wt = 6000, 500, 5, 32, 32, 4
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: (torch.randn(*s, generator=gen) * 0.3).to(DEV)
+    idx = torch.randint(0, n_nbr + 1, (n, k), generator=gen)
+    idx[:, 0] = 7                                             # every node lists destination 6 -> a long row
+    idx[::3, 1] = 0                                           # pads
+    idx32 = idx.to(DEV).to(torch.int32)
+    widx32 = torch.randint(0, n_wt, (n, k), generator=gen).to(DEV).to(torch.int32)
+    base = [rnd(n, A), rnd(n_nbr, A), rnd(n_wt, A), rnd(A), rnd(n_nbr, D)]
+    d_out = torch.zeros(n, D, device=DEV)
+    rows = torch.randperm(n, generator=gen)[:2500].to(DEV)
+    d_out[rows] = rnd(2500, D)
+    grads = []
+    old, old_pull = TG._SPARSE_MIN_ROWS, TG._PULL_MIN_ROWS
+    try:
+        for pull in (10 ** 9, 0):
+            TG._SPARSE_MIN_ROWS, TG._PULL_MIN_ROWS = 0, pull
+            xs = [b.clone().requires_grad_() for b in base]
+            TG.neighbour_attention(xs[0], xs[1], xs[2], xs[3], xs[4], idx32, widx32, None).backward(d_out)
+            grads.append([x.grad.clone() for x in xs])
+    finally:
+        TG._SPARSE_MIN_ROWS, TG._PULL_MIN_ROWS = old, old_pull
+    for a, b in zip(*grads):
+        scale = float(a.abs().max()) + 1e-30
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=3e-6 * scale)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Per-step kernel breakdown from a `rocprofv3 --kernel-trace --output-format csv` run of bench.py.
+
+    python3 tools/step_trace.py <dir with *_kernel_trace.csv> [out.csv]
+
+A training step ends with a burst of `adam_kernel` launches (one per parameter tensor), so the trace is cut at the end
+of every burst; the LAST complete window that is preceded by another burst is one steady-state step.  Prints, for that
+step, the time per kernel name (sum, calls, mean, max), the busy time and the idle gaps between kernels."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    d = sys.argv[1]
+    path = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[0]
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    # bursts of adam kernels: consecutive adam launches with < 2 ms between them
+    ends = []
+    last = None
+    for s, e, n in rows:
+        if "adam_kernel" in n:
+            if last is not None and s - last > 2_000_000:
+                ends.append(last)
+            last = e
+    if last is not None:
+        ends.append(last)
+    which = int(os.environ.get("STEP", "-1"))
+    if len(ends) < 2:
+        sys.exit("fewer than two optimizer bursts in the trace")
+    for i in range(1, len(ends)):
+        n_in = sum(1 for s, e, n in rows if s > ends[i - 1] and e <= ends[i])
+        print(f"# window {i - len(ends)}: {(ends[i] - ends[i - 1]) / 1e6:.2f} ms, {n_in} launches")
+    hi = ends[which]
+    lo = ends[which - 1]
+    step = [(s, e, n) for s, e, n in rows if s > lo and e <= hi]
+    agg = defaultdict(lambda: [0, 0, 0])
+    busy, gap, prev = 0, 0, lo
+    for s, e, n in step:
+        a = agg[n]
+        a[0] += e - s
+        a[1] += 1
+        a[2] = max(a[2], e - s)
+        busy += e - s
+        if s > prev:
+            gap += s - prev
+        prev = max(prev, e)
+    wall = hi - lo
+    out = [("kernel", "total_ms", "calls", "mean_us", "max_us", "share")]
+    for n, (t, c, m) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        out.append((n[:110], f"{t / 1e6:.3f}", c, f"{t / c / 1e3:.1f}", f"{m / 1e3:.1f}", f"{t / wall:.3f}"))
+    print(f"# {path}\n# step window {wall / 1e6:.2f} ms, kernels busy {busy / 1e6:.2f} ms, idle gaps {gap / 1e6:.2f} ms, "
+          f"{len(step)} launches, {len(ends)} optimizer bursts in the trace")
+    w = csv.writer(open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout)
+    w.writerows(out)
+
+
+if __name__ == "__main__":
+    main()
