@@ -344,10 +344,12 @@ class _Layer(nn.Module):
         return outs
 
 
-    def forward_rows(self, emb, ewp, nbr, rows_out, rows_in, chunk_rows, use_checkpoint, fused=True, inv=None):
-        """`forward` restricted to the rows a mini-batch's loss depends on.  emb[t]: full-size input tables, valid on
-        rows_in[t] (None = every row); rows_out[t]: rows whose outputs are wanted (None = every row; a subset of
-        rows_in[t]).  Returns {type: outputs of those rows, in that order}."""
+    def forward_rows(self, emb, ewp, nbr, rows_out, rows_in, pos_in, chunk_rows, use_checkpoint, fused=True, inv=None):
+        """`forward` restricted to the rows a mini-batch's loss depends on, on COMPACT tables.  emb[t]: the input table
+        of type t -- all rows when rows_in[t] is None, otherwise only the rows rows_in[t] (in that order), with
+        pos_in[t][id + 1] = 1 + position of node id in it (int32, 0 for the pad id).  rows_out[t]: rows whose outputs
+        are wanted (None = every row; otherwise a subset of rows_in[t] that also holds every neighbour of those rows).
+        Returns {type: outputs of those rows, in that order}."""
         D = self.in_features
         inv = inv if inv is not None else [None] * 6
         others = {"user": ("item", "tag"), "item": ("user", "tag"), "tag": ("user", "item")}
@@ -355,10 +357,11 @@ class _Layer(nn.Module):
         pick = lambda x, rows: x if rows is None else x.index_select(0, rows)
         Q, P, selfv = {}, {}, {}
         for t, (n1, n2) in others.items():
-            # Q_t = e_t W2 is read wherever t is the NEIGHBOUR type: needed on rows_in[t]
-            q = pick(emb[t], rows_in[t]) @ self.atten1[t].W_2
-            Q[t] = q if rows_in[t] is None else q.new_zeros(emb[t].shape[0], A).index_copy_(0, rows_in[t], q)
-            selfv[t] = pick(emb[t], rows_out[t])
+            Q[t] = emb[t] @ self.atten1[t].W_2              # read wherever t is the NEIGHBOUR type: rows_in[t]
+            if rows_out[t] is None or rows_in[t] is None:
+                selfv[t] = pick(emb[t], rows_out[t])
+            else:
+                selfv[t] = emb[t].index_select(0, pos_in[t].index_select(0, rows_out[t] + 1).long() - 1)
             y = selfv[t] @ torch.cat([self.atten1[n1].W_1[:D], self.atten1[n2].W_1[:D]], dim=1)
             P[(t, n1)] = y[:, :A] + self.atten1[n1].b
             P[(t, n2)] = y[:, A:] + self.atten1[n2].b
@@ -370,8 +373,10 @@ class _Layer(nn.Module):
             if rows is not None and rows.numel() == 0:
                 return emb[nb].new_zeros(0, D)
             idx, widx = pick(nbr[r][0], rows), pick(nbr[r][1], rows)
+            if rows_in[nb] is not None:                      # neighbour ids -> positions in the compact table
+                idx = pos_in[nb].index_select(0, idx.flatten().long()).reshape(idx.shape)
             return neighbour_attention(P[(src, nb)].contiguous(), Q[nb], WT[nb], a.v.reshape(-1), emb[nb], idx, widx,
-                                       inv[r] if rows is None else None)
+                                       inv[r] if rows is None and rows_in[nb] is None else None)
 
         eu_i, eu_t = att("user", "item", 0), att("user", "tag", 1)
         ei_u, ei_t = att("item", "user", 2), att("item", "tag", 3)
@@ -588,39 +593,48 @@ class TGCN(nn.Module):
         return need
 
     def _forward_rows(self, batch):
-        """The forward pass restricted, layer by layer, to `_needed_rows`: identical outputs on the batch rows (the
-        only rows the loss reads), zeros elsewhere.  Bounded fan-in (k sampled neighbours) is what makes this pay
-        for TGCN: the top layer runs on the <= 3 B batch rows, the one below on <= 2 k of those per row."""
+        """The forward pass restricted, layer by layer, to `_needed_rows`, on compact tables (a layer's output holds
+        only the rows the next layer reads; neighbour ids are renumbered into it).  Returns (users, items, triplets):
+        the concatenated layer outputs of the batch's distinct users / items and the batch renumbered into those
+        tables -- the same rows `forward()` would give the loss.  Bounded fan-in (k sampled neighbours) is what makes
+        this pay for TGCN: the top layer runs on the <= 3 B batch rows, the one below on <= 2 k of those per row."""
         need = self._needed_rows(batch)
+        sizes = {"user": self.num_user, "item": self.num_item, "tag": self.num_tag}
         ew = self.embed["weight"]
         ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])
         emb = {"user": self.embed["user"], "item": self.embed["item"], "tag": self.embed["tag"]}
-        cat = {t: [e] for t, e in emb.items()}
+        top = need[len(self.layer)]
+        at_top = lambda z, rows, pos, t: z.index_select(0, top[t] if rows is None else pos.index_select(0, top[t] + 1).long() - 1)
+        cat = {t: [emb[t].index_select(0, top[t])] for t in ("user", "item")}
         rows_in = {t: None for t in emb}
+        pos_in = {t: None for t in emb}
         for i, layer in enumerate(self.layer.values()):
             rows_out = need[i + 1]
-            outs = layer.forward_rows(emb, ewp, self.nbr, rows_out, rows_in, self.chunk_rows, self.use_checkpoint,
+            outs = layer.forward_rows(emb, ewp, self.nbr, rows_out, rows_in, pos_in, self.chunk_rows, self.use_checkpoint,
                                       self.fused_dense, self.inv)
             p = self.message_drop_list[i]
-            nxt = {}
+            nxt, pos_out = {}, {}
             for t, o in outs.items():
                 if self.training and p > 0:
                     o = torch.nn.functional.dropout(o, p=p, training=True)
-                z = H.normalize_rows(o) if o.shape[0] else o
-                if rows_out[t] is None:
-                    nxt[t] = o
-                    cat[t].append(z)
-                else:
-                    n = emb[t].shape[0]
-                    nxt[t] = o.new_zeros(n, o.shape[1]).index_copy_(0, rows_out[t], o)
-                    cat[t].append(z.new_zeros(n, z.shape[1]).index_copy_(0, rows_out[t], z))
-            emb, rows_in = nxt, rows_out
-        return torch.cat(cat["user"], dim=1), torch.cat(cat["item"], dim=1)
+                nxt[t] = o
+                pos_out[t] = None
+                if rows_out[t] is not None:
+                    pos_out[t] = torch.zeros(sizes[t] + 1, dtype=torch.int32, device=self.device)
+                    pos_out[t][rows_out[t] + 1] = torch.arange(1, rows_out[t].numel() + 1, dtype=torch.int32, device=self.device)
+                if t in cat:                                    # the loss reads the normalised rows of the batch only
+                    ot = at_top(o, rows_out[t], pos_out[t], t)
+                    cat[t].append(H.normalize_rows(ot) if ot.shape[0] else ot)
+            emb, rows_in, pos_in = nxt, rows_out, pos_out
+        trip = torch.stack([torch.searchsorted(top["user"], batch[:, 0].contiguous()),
+                            torch.searchsorted(top["item"], batch[:, 1].contiguous()),
+                            torch.searchsorted(top["item"], batch[:, 2].contiguous())], dim=1)
+        return torch.cat(cat["user"], dim=1), torch.cat(cat["item"], dim=1), trip
 
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
         if self.prune_forward and self.training and not torch.cuda.is_current_stream_capturing():
-            all_users, all_items = self._forward_rows(batch_data)
+            all_users, all_items, batch_data = self._forward_rows(batch_data)
         else:
             all_users, all_items = self.forward()[:2]
         loss, reg_loss = H.triplet_loss(all_users, all_items, all_users, all_items, batch_data, self.loss_func)
