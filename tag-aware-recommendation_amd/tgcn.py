@@ -52,6 +52,36 @@ class InverseTable:
                        (n_dst, n))
 
 
+class _TallMM(torch.autograd.Function):
+    """X [n, d] @ W [d, a] for n in the millions (the Q / P projections over a node table).  The weight gradient
+    X^T dY is a product with n on the contraction axis and a tiny output, for which the library picks one wave-starved
+    kernel (2.4 ms for 2 M x 128 x 32, 0.5 TB/s); cut n into slabs, one small product per slab, and add the slabs."""
+    SLABS = 256
+
+    @staticmethod
+    def forward(ctx, X, W):
+        ctx.save_for_backward(X, W)
+        return X @ W
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        dX = dY @ W.t() if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            X, dY = X.contiguous(), dY.contiguous()
+            n, S = X.shape[0], _TallMM.SLABS
+            m = n // S * S
+            dW = torch.bmm(X[:m].view(S, m // S, -1).transpose(1, 2), dY[:m].view(S, m // S, -1)).sum(0)
+            if m < n:
+                dW = dW + X[m:].t() @ dY[m:]
+        return dX, dW
+
+
+def _tall_mm(X, W):
+    return _TallMM.apply(X, W) if X.shape[0] >= 65536 else X @ W
+
+
 def _pull_compact(idxc, attnc, doc, dh, n_dst):
     """dQ = S dh and dEj = G dOut for a COMPACT set of source rows (`InverseTable` built on the spot: one radix sort of
     the rows' n k neighbour ids; pad slots sort behind the last destination row and are never read)."""
@@ -325,7 +355,7 @@ class _Layer(nn.Module):
         Q, P = {}, {}
         for t, (n1, n2) in others.items():
             wcat = torch.cat([self.atten1[t].W_2, self.atten1[n1].W_1[:D], self.atten1[n2].W_1[:D]], dim=1)
-            y = emb[t] @ wcat
+            y = _tall_mm(emb[t], wcat)
             Q[t] = y[:, :A]
             P[(t, n1)] = y[:, A:2 * A] + self.atten1[n1].b
             P[(t, n2)] = y[:, 2 * A:] + self.atten1[n2].b
@@ -357,12 +387,12 @@ class _Layer(nn.Module):
         pick = lambda x, rows: x if rows is None else x.index_select(0, rows)
         Q, P, selfv = {}, {}, {}
         for t, (n1, n2) in others.items():
-            Q[t] = emb[t] @ self.atten1[t].W_2              # read wherever t is the NEIGHBOUR type: rows_in[t]
+            Q[t] = _tall_mm(emb[t], self.atten1[t].W_2)     # read wherever t is the NEIGHBOUR type: rows_in[t]
             if rows_out[t] is None or rows_in[t] is None:
                 selfv[t] = pick(emb[t], rows_out[t])
             else:
                 selfv[t] = emb[t].index_select(0, pos_in[t].index_select(0, rows_out[t] + 1).long() - 1)
-            y = selfv[t] @ torch.cat([self.atten1[n1].W_1[:D], self.atten1[n2].W_1[:D]], dim=1)
+            y = _tall_mm(selfv[t], torch.cat([self.atten1[n1].W_1[:D], self.atten1[n2].W_1[:D]], dim=1))
             P[(t, n1)] = y[:, :A] + self.atten1[n1].b
             P[(t, n2)] = y[:, A:] + self.atten1[n2].b
         WT = {t: ewp @ self.atten1[t].W_1[D:] for t in emb}

@@ -418,3 +418,18 @@ def test_compact_pull_backward_with_a_popular_neighbour():
     for a, b in zip(*grads):
         scale = float(a.abs().max()) + 1e-30
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=3e-6 * scale)
+
+
+def test_tall_projection_weight_gradient_by_slabs():
+    """`_TallMM`: X @ W whose weight gradient is summed slab by slab (n not a multiple of the slab count)."""
+    from tagrec_amd import tgcn as TG
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    X = torch.randn(70_001, 64, generator=gen).to(DEV).requires_grad_()
+    W = (torch.randn(64, 32, generator=gen) * 0.1).to(DEV).requires_grad_()
+    dY = torch.randn(70_001, 32, generator=gen).to(DEV)
+    TG._tall_mm(X, W).backward(dY)
+    gx, gw = X.grad.clone(), W.grad.clone()
+    ref_w = (X.detach().double().t() @ dY.double())
+    ref_x = dY.double() @ W.detach().double().t()
+    assert float((gw.double() - ref_w).abs().max()) <= 1e-5 * float(ref_w.abs().max())
+    assert float((gx.double() - ref_x).abs().max()) <= 1e-5 * float(ref_x.abs().max())
