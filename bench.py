@@ -67,7 +67,6 @@ def spmm_bytes(nnz, n_rows, D, epilogue_row_bytes):
 
 def cpu_baseline(args, full_nnz):
     """CPU oracle step time on a 1/32-scale C2-shaped graph, scaled to the full graph by stored entries."""
-    import numpy as np
     import tagrec_amd as T
     from oracle import adj as oadj, models as om
     frac = 32 if args.scale >= 0.5 else 1

@@ -13,7 +13,6 @@ Differences in mechanism, not in results:
     backward is hand-derived: BPR scatter, then one fused SpMM + normalise-backward per layer.
 """
 import torch
-import torch.nn as nn
 
 from . import _lib, help as H
 from .base import TableModel, xavier_tables  # noqa: F401  (xavier_tables re-exported)
