@@ -409,6 +409,12 @@ int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n
 // gradients, dS [n, 3 A] type-attention pre-activation gradients.  The tiny parameter gradients that are plain
 // sums over nodes (dwb [32,3], dq [A], dp [A]) are accumulated per block in LDS and written as
 // per-block partials [block][96 + 2 A]; dbf is a column sum the caller takes.
+//
+// Where the time goes at D = Dout = 128 (1 M nodes, 18.2 ms; ablations on an MI355X, each part removed in turn):
+// MFMAs of the main loop 7.5 ms, its VALU part 2.7 ms, its LDS reads 2.0 ms, barriers + DMA waits 2.0 ms, per-tile
+// prologue / epilogue 4.4 ms -- the parts ADD UP: with 512 registers per wave only one wave fits a SIMD and nothing
+// overlaps.  Pipelining inside the wave (the piece rotation and the three-buffer ring below) recovers ~3 %; the lever
+// is a second wave per SIMD, i.e. the e / de accumulators (192 registers) split over two waves or two passes.
 template <int D, int DOUT, int A, bool LDSW>
 __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
     const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, int64_t n,
@@ -427,7 +433,13 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
   // (rows {0-3,12-15} of one quarter q and {4-11} of the next) fall on 16 distinct bank slots.
   constexpr int NB = 2;                      // b-steps (16 weight rows each) per staged chunk: a barrier every 2 x Dout/4 MFMAs
   constexpr int RP = 256 / DOUT, PPW = (NB * 16 / RP) / 4, CHUNK = NB * 16 * DOUT * 4;
-  __shared__ __attribute__((aligned(1024))) char wbuf[LDSW ? 2 : 1][LDSW ? CHUNK : 16];
+  // The chunks form ONE periodic stream over the whole kernel (the weight rows do not depend on the tile): a ring of
+  // three buffers, chunk i + 2 issued when chunk i is entered, so a chunk has two chunk-times (~1.7 us of MFMA work)
+  // to arrive from L2; waits are counted (`s_waitcnt vmcnt(PPW)` + a raw s_barrier), never the vmcnt(0) of
+  // __syncthreads(), which would drain the chunk just issued.
+  constexpr int NBUF = 3, CPC = IB / NB, NCH = kBitC * CPC;
+  static_assert(!LDSW || CPC >= 2, "ring prologue issues two chunks of filter 0");
+  __shared__ __attribute__((aligned(1024))) char wbuf[LDSW ? NBUF : 1][LDSW ? CHUNK : 16];
   for (int i = threadIdx.x; i < NSM; i += kFuseThreads) sh[i] = 0.f;
   __syncthreads();
   float* sh_wb = sh;
@@ -454,23 +466,26 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
   const int64_t it_first = LDSW ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) * 4 + wave;
   const int64_t it_step = LDSW ? static_cast<int64_t>(gridDim.x) : static_cast<int64_t>(gridDim.x) * 4;
   const int64_t it_end = LDSW ? (n_tiles + 3) / 4 : n_tiles;
+  auto issue = [&](int c, int b, int buf) {              // rows of steps b .. b + NB - 1 of filter c
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int p = wave * PPW + j;
+      const int lrow = p * RP + dma_row;                                      // chunk row = (step, MFMA row i)
+      const int sub = lrow >> 4, i = lrow & 15;
+      const int u = dma_unit ^ swz(i);
+      const float* src = Wf + (static_cast<int64_t>(c) * D + (i >> 2) * DS + (i & 3) + 4 * (b + sub)) * DOUT + u * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)&wbuf[buf][p * 1024], 16, 0, 0);
+    }
+  };
+  int cur = 0;                                           // ring slot of the chunk being consumed (block-uniform)
+  if constexpr (LDSW)
+    if (it_first < it_end) { issue(0, 0, 0); issue(0, NB, 1); }
   for (int64_t it = it_first; it < it_end; it += it_step) {
     const int64_t tile = LDSW ? it * 4 + wave : it;
+    const bool has_next = it + it_step < it_end;
     U = fresh(U); qv = fresh(qv); pv = fresh(pv); wb = fresh(wb); w1 = fresh(w1); w2 = fresh(w2); w3 = fresh(w3);
     Wf = fresh(Wf);
-    auto issue = [&](int c, int b, int buf) {            // rows of steps b .. b + NB - 1 of filter c
-#pragma unroll
-      for (int j = 0; j < PPW; ++j) {
-        const int p = wave * PPW + j;
-        const int lrow = p * RP + dma_row;                                    // chunk row = (step, MFMA row i)
-        const int sub = lrow >> 4, i = lrow & 15;
-        const int u = dma_unit ^ swz(i);
-        const float* src = Wf + (static_cast<int64_t>(c) * D + (i >> 2) * DS + (i & 3) + 4 * (b + sub)) * DOUT + u * 4;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)&wbuf[buf][p * 1024], 16, 0, 0);
-      }
-    };
-    if constexpr (LDSW) issue(0, 0, 0);
     const int64_t node = tile * 16 + r;
     const bool ok = node < n;
     float e3[3][DS];
@@ -509,29 +524,57 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
         float a[OS];
         if constexpr (LDSW) {
           if (b % NB == 0) {
-            __syncthreads();                             // the chunk holding steps b .. b+NB-1 has landed; the other buffer is free
-            if (b + NB < IB) issue(c, b + NB, ((b / NB) + 1) & 1);
-            else if (c + 1 < kBitC) issue(c + 1, 0, 0);
+            const int j = c * CPC + b / NB;              // chunk number inside the tile
+            // chunk j + 1 may still be in flight (it exists unless this is the very last chunk of the block's work)
+            if (j + 1 < NCH || has_next) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // chunk j is in LDS for every wave; everyone is done with chunk j - 1
+            int j2 = j + 2;
+            const bool wrap = j2 >= NCH;                 // the stream continues with the next tile group's first chunks
+            if (wrap) j2 -= NCH;
+            if (!wrap || has_next) issue(j2 / CPC, (j2 % CPC) * NB, cur >= 1 ? cur - 1 : NBUF - 1);
           }
-          const char* rowp = &wbuf[(b / NB) & 1][((b % NB) * 16 + r) * DOUT * 4];
+        }
+        f32x4 dy = zero4(), dy1 = zero4();
+        if constexpr (LDSW) {
+          // The allocator has no room for the 32 weight values of a step (the kernel sits at the register limit), and
+          // left to itself reads one 16-byte piece, waits, issues its 4 MFMAs, reads the next: the LDS latency is
+          // exposed 8 times per step.  Written out as a rotation over three pieces -- two reads always in flight
+          // behind the MFMAs of the current piece -- it costs 8 more registers and hides it.
+          const char* rowp = &wbuf[cur][((b % NB) * 16 + r) * DOUT * 4];
           const int sw = swz(r);
+          auto piece = [&](int t4) { return *reinterpret_cast<const float4*>(rowp + (((q * (OS / 4) + t4) ^ sw) << 4)); };
+          float4 w0 = piece(0), w1_ = piece(1 < OS / 4 ? 1 : 0);
 #pragma unroll
-          for (int t = 0; t < OS; t += 4) {
-            const float4 w4 = *reinterpret_cast<const float4*>(rowp + (((q * (OS / 4) + t / 4) ^ sw) << 4));
-            a[t] = w4.x; a[t + 1] = w4.y; a[t + 2] = w4.z; a[t + 3] = w4.w;
+          for (int t4 = 0; t4 < OS / 4; ++t4) {
+            const float4 w2_ = piece(t4 + 2 < OS / 4 ? t4 + 2 : t4);
+            const int t = 4 * t4;
+            dy = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, g[t], dy, 0, 0, 0);
+            dy1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, g[t + 1], dy1, 0, 0, 0);
+            dy = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, g[t + 2], dy, 0, 0, 0);
+            dy1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, g[t + 3], dy1, 0, 0, 0);
+            w0 = w1_; w1_ = w2_;
+          }
+          // pin that order (the scheduler otherwise sinks every read down to its use to save registers)
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+          for (int t4 = 0; t4 < OS / 4; ++t4) {
+            if (t4 + 2 < OS / 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
           }
         } else {
 #pragma unroll
           for (int t = 0; t < OS; ++t) a[t] = a_next[t];
           load_run<OS>(b + 1 < IB ? wrow + static_cast<int64_t>(4 * (b + 1)) * DOUT : wrow_next, a_next);
-        }
-        f32x4 dy = zero4(), dy1 = zero4();
 #pragma unroll
-        for (int t = 0; t < OS; t += 2) {
-          dy = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], g[t], dy, 0, 0, 0);
-          dy1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 1], g[t + 1], dy1, 0, 0, 0);
+          for (int t = 0; t < OS; t += 2) {
+            dy = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], g[t], dy, 0, 0, 0);
+            dy1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 1], g[t + 1], dy1, 0, 0, 0);
+          }
         }
         dy += dy1;
+        if constexpr (LDSW)
+          if (b % NB == NB - 1) cur = cur == NBUF - 1 ? 0 : cur + 1;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int e = 4 * b + v;
