@@ -21,7 +21,7 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused
 (8+4D) per stored entry + (8+4D) per row + 8D per row for the fused normalise/mean epilogue)
 divided by its mean duration from HIP events recorded on the launch stream inside the timed region.
 `cpu_baseline` times the CPU oracle (PyTorch CPU restatement of the reference path, checked against
-the reference in tests/golden) on a 1/32-scale graph of the same shape and scales by stored entries.
+the reference in tests/golden) on a 1/8-scale graph of the same shape and scales by stored entries.
 """
 import argparse
 import json
@@ -66,10 +66,11 @@ def spmm_bytes(nnz, n_rows, D, epilogue_row_bytes):
 
 
 def cpu_baseline(args, full_nnz):
-    """CPU oracle step time on a 1/32-scale C2-shaped graph, scaled to the full graph by stored entries."""
+    """CPU oracle step time on a 1/8-scale C2-shaped graph (about 15 s of CPU work), scaled to the full graph by stored
+    entries."""
     import tagrec_amd as T
     from oracle import adj as oadj, models as om
-    frac = 32 if args.scale >= 0.5 else 1
+    frac = 8 if args.scale >= 0.5 else 1
     nu = max(int(1_000_000 * args.scale) // frac, 1000)
     ne = max(int(50_000_000 * args.scale) // frac, 20000)
     # the GPU box gives one-GPU jobs a 16-core share of the host; more threads only oversubscribe it
@@ -83,7 +84,7 @@ def cpu_baseline(args, full_nnz):
     tabs = [t.requires_grad_() for t in om.xavier_tables([(nu, args.dim), (nu, args.dim)], 2020)]
     opt = torch.optim.Adam(tabs, lr=0.01)
     g = torch.Generator().manual_seed(5)
-    n_warm, n_timed = 1, 4
+    n_warm, n_timed = 1, 3
     pick = torch.randint(0, e.shape[0], ((n_warm + n_timed) * args.batch,), generator=g)
     tri = torch.stack([e[pick, 0], e[pick, 1], torch.randint(0, nu, (pick.numel(),), generator=g)], 1)
     batches = [tri[k * args.batch:(k + 1) * args.batch] for k in range(n_warm + n_timed)]
