@@ -143,3 +143,30 @@ def test_early_stop_protocol(tmp_path):
     assert es(model, {"ndcg": [0.4, 0.9]}, 5) is False and es.count_step == 1       # worse @10 although better @20
     assert es(model, {"ndcg": [0.45, 0.9]}, 10) is True                             # count 2 > patient 1
     assert es.best_result == {"ndcg": [0.5, 0.6]}
+
+
+def test_step_trace_tool_cuts_at_optimizer_bursts(tmp_path):
+    """tools/step_trace.py on a synthetic rocprofv3 kernel trace: the window between two bursts of `adam_kernel`
+    launches is one step; per-kernel totals, busy time and idle gaps of that window."""
+    import subprocess
+    import sys
+    d = tmp_path / "run" / "1"
+    d.mkdir(parents=True)
+    rows, t = [], 0
+    for step in range(3):
+        for name, dur in (("spmm_rows_kernel", 3_000_000), ("bpr_fwd_kernel", 10_000), ("spmm_rows_kernel", 2_000_000)):
+            rows.append((t, t + dur, name)); t += dur + 5_000
+        for _ in range(2):
+            rows.append((t, t + 50_000, "tagrec::adam_kernel(float4*)")); t += 60_000
+        t += 3_000_000                                   # host gap before the next step (> 2 ms: ends the burst)
+    with open(d / "1_kernel_trace.csv", "w") as f:
+        f.write("Kind,Agent_Id,Kernel_Name,Start_Timestamp,End_Timestamp\n")
+        for s, e, n in rows:
+            f.write(f'KERNEL_DISPATCH,0,"{n}",{s},{e}\n')
+    out = tmp_path / "step.csv"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_trace.py"), str(tmp_path / "run"), str(out)],
+                       capture_output=True, text=True, check=True)
+    assert "3 optimizer bursts" in r.stdout and "step window 8.14 ms" in r.stdout and ", 5 launches" in r.stdout
+    table = {row[0]: row for row in __import__("csv").reader(open(out))}
+    assert float(table["spmm_rows_kernel"][1]) == 5.0 and int(table["spmm_rows_kernel"][2]) == 2
+    assert int(table["tagrec::adam_kernel(float4*)"][2]) == 2

@@ -102,6 +102,26 @@ def test_spmm_long_rows_and_empty_rows(D):
     assert torch.equal(got, again)
 
 
+def test_graph_like_shares_the_long_row_list():
+    """`Graph.like`: a second matrix over the same row pointer (own columns / values, another column count) gives
+    the product of a graph created from scratch, long rows included, and outlives nothing it does not hold."""
+    rng = np.random.RandomState(2)
+    csr = _star_graph(6000, 5000, rng)
+    g = _graph(csr)
+    gen = torch.Generator().manual_seed(4)
+    col2 = torch.randint(0, 777, (g.nnz,), generator=gen, dtype=torch.int32).to(DEV)
+    val2 = torch.randn(g.nnz, generator=gen).to(DEV)
+    twin = g.like(col2, val2, 777)
+    fresh = T.Graph(g.rowptr, col2, val2, (6000, 777))
+    assert twin.info()["n_long_rows"] == fresh.info()["n_long_rows"] == 2 and twin.shape == (6000, 777)
+    X = torch.randn(777, 64, generator=gen).to(DEV)
+    assert torch.equal(twin.spmm(X), fresh.spmm(X))
+    with pytest.raises(T.TagrecError):
+        g.like(col2[:-1], val2[:-1], 777)
+    del g                                   # the twin keeps its parent (and the shared work list) alive
+    assert torch.equal(twin.spmm(X), fresh.spmm(X))
+
+
 def test_spmm_rejects_bad_arguments():
     rng = np.random.RandomState(1)
     csr = oadj.coo_to_csr(rng.randint(0, 100, 500), rng.randint(0, 100, 500), rng.rand(500), (100, 100))
