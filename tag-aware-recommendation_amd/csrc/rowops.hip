@@ -76,6 +76,67 @@ __global__ __launch_bounds__(kThreads) void rownorm_bwd_kernel(const float* __re
   }
 }
 
+// The same for D = 4 LPR in {8 .. 256}, not accumulating: LPR lanes x 16 B per row, 64 / LPR rows per wavefront.  At the
+// head of the backward chain dZ is zero outside the <= 3 B batch rows, so nearly every row is "read 4 D bytes, write 4 D
+// zero bytes": one float per lane and one row per wave (the kernel above) leaves too few bytes in flight for that.
+template <int LPR>
+__global__ __launch_bounds__(kThreads) void rownorm_bwd_vec_kernel(const float* __restrict__ Xraw,
+                                                                   const float* __restrict__ inv_norm,
+                                                                   const float* __restrict__ dZ, int64_t lddz, float s,
+                                                                   float* __restrict__ dX, int64_t n_rows,
+                                                                   uint8_t* __restrict__ row_flags) {
+  constexpr int NPI = kWave / LPR;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int grp = lane / LPR, c4 = lane % LPR;
+  const int64_t r = (static_cast<int64_t>(blockIdx.x) * (kThreads / kWave) + (threadIdx.x >> 6)) * NPI + grp;
+  const bool ok = r < n_rows;
+  float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) dz = *reinterpret_cast<const float4*>(dZ + r * lddz + 4 * c4);
+  const unsigned long long lanes = __ballot(dz.x != 0.f || dz.y != 0.f || dz.z != 0.f || dz.w != 0.f);
+  const unsigned long long mine = LPR == kWave ? lanes : (lanes >> (grp * LPR)) & ((1ull << (LPR % kWave)) - 1);
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool nz = false;
+  if (mine != 0) {                                   // uniform over the row's lane group
+    const float inv = inv_norm[r];
+    const float4 x = *reinterpret_cast<const float4*>(Xraw + r * (4 * LPR) + 4 * c4);
+    float dot = fmaf(x.x * inv, dz.x * s, fmaf(x.y * inv, dz.y * s, fmaf(x.z * inv, dz.z * s, (x.w * inv) * (dz.w * s))));
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) dot += __shfl_xor(dot, m);
+    if (inv >= 1e12f) dot = 0.f;                     // norm was clamped to eps: the denominator is a constant
+    g = make_float4(inv * (dz.x * s - x.x * inv * dot), inv * (dz.y * s - x.y * inv * dot),
+                    inv * (dz.z * s - x.z * inv * dot), inv * (dz.w * s - x.w * inv * dot));
+    nz = g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f;
+  }
+  const unsigned long long nzl = __ballot(nz);
+  if (!ok) return;
+  *reinterpret_cast<float4*>(dX + r * (4 * LPR) + 4 * c4) = g;
+  if (row_flags && c4 == 0)
+    row_flags[r] = (LPR == kWave ? nzl : (nzl >> (grp * LPR)) & ((1ull << (LPR % kWave)) - 1)) != 0;
+}
+
+template <int LPR>
+static void launch_rownorm_bwd_vec(const float* X_raw, const float* inv_norm, const float* dZ, int64_t lddz, float s, float* dX,
+                                   int64_t n_rows, uint8_t* row_flags, hipStream_t st) {
+  const int64_t rows_per_block = (kThreads / kWave) * (kWave / LPR);
+  rownorm_bwd_vec_kernel<LPR><<<static_cast<unsigned>((n_rows + rows_per_block - 1) / rows_per_block), kThreads, 0, st>>>(
+      X_raw, inv_norm, dZ, lddz, s, dX, n_rows, row_flags);
+}
+
+// true (and launched) when the vector kernel applies: D = 8 .. 256 a power of two, rows 16-byte aligned
+static bool rownorm_bwd_vec(const float* X_raw, const float* inv_norm, const float* dZ, int64_t lddz, float s, float* dX,
+                            int64_t n_rows, int D, uint8_t* row_flags, hipStream_t st) {
+  if (!(aligned16(X_raw) && aligned16(dZ) && aligned16(dX) && lddz % 4 == 0)) return false;
+  switch (D) {
+    case 8: launch_rownorm_bwd_vec<2>(X_raw, inv_norm, dZ, lddz, s, dX, n_rows, row_flags, st); return true;
+    case 16: launch_rownorm_bwd_vec<4>(X_raw, inv_norm, dZ, lddz, s, dX, n_rows, row_flags, st); return true;
+    case 32: launch_rownorm_bwd_vec<8>(X_raw, inv_norm, dZ, lddz, s, dX, n_rows, row_flags, st); return true;
+    case 64: launch_rownorm_bwd_vec<16>(X_raw, inv_norm, dZ, lddz, s, dX, n_rows, row_flags, st); return true;
+    case 128: launch_rownorm_bwd_vec<32>(X_raw, inv_norm, dZ, lddz, s, dX, n_rows, row_flags, st); return true;
+    case 256: launch_rownorm_bwd_vec<64>(X_raw, inv_norm, dZ, lddz, s, dX, n_rows, row_flags, st); return true;
+    default: return false;
+  }
+}
+
 // row_flags[r] = 1 iff row r of X [n, D] holds a non-zero
 __global__ __launch_bounds__(kThreads) void row_flags_kernel(const float* __restrict__ X, int64_t n_rows, int D,
                                                              uint8_t* __restrict__ row_flags) {
@@ -450,8 +511,9 @@ extern "C" int tagrec_rownorm_bwd_f32(const float* X_raw, const float* inv_norm,
   TAGREC_REQUIRE(n_rows >= 0 && D >= 1 && lddz >= D, "rownorm_bwd: bad shape");
   if (n_rows == 0) return TAGREC_OK;
   const unsigned blocks = static_cast<unsigned>((n_rows + 3) / 4);
-  rownorm_bwd_kernel<<<blocks, kThreads, 0, static_cast<hipStream_t>(stream)>>>(X_raw, inv_norm, dZ, lddz, d_scale, dX,
-                                                                                accumulate, n_rows, D, nullptr);
+  if (accumulate || !rownorm_bwd_vec(X_raw, inv_norm, dZ, lddz, d_scale, dX, n_rows, D, nullptr, static_cast<hipStream_t>(stream)))
+    rownorm_bwd_kernel<<<blocks, kThreads, 0, static_cast<hipStream_t>(stream)>>>(X_raw, inv_norm, dZ, lddz, d_scale, dX,
+                                                                                  accumulate, n_rows, D, nullptr);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
@@ -475,8 +537,9 @@ extern "C" int tagrec_rownorm_bwd_flags_f32(const float* X_raw, const float* inv
   TAGREC_REQUIRE(n_rows >= 0 && D >= 1 && lddz >= D, "rownorm_bwd_flags: bad shape");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n_rows > 0) {
-    rownorm_bwd_kernel<<<static_cast<unsigned>((n_rows + 3) / 4), kThreads, 0, s>>>(X_raw, inv_norm, dZ, lddz, d_scale, dX,
-                                                                                   accumulate, n_rows, D, row_flags);
+    if (accumulate || !rownorm_bwd_vec(X_raw, inv_norm, dZ, lddz, d_scale, dX, n_rows, D, row_flags, s))
+      rownorm_bwd_kernel<<<static_cast<unsigned>((n_rows + 3) / 4), kThreads, 0, s>>>(X_raw, inv_norm, dZ, lddz, d_scale, dX,
+                                                                                     accumulate, n_rows, D, row_flags);
     TAGREC_LAUNCH_CHECK();
   }
   return count_flags(row_flags, n_rows, count, s);
