@@ -189,10 +189,22 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void route_spmm_finish_kern
   const int64_t deg = g.rowptr[r + 1] - g.rowptr[r];
   const int nc = static_cast<int>((deg + kChunk - 1) / kChunk);
   const float4* p = reinterpret_cast<const float4*>(slab) + static_cast<int64_t>(long_base[li]) * LPR + (lane % LPR);
+  // lane group q sums the chunks q, q + NPI, ... in ascending order, then an xor butterfly over the groups (fixed order;
+  // see spmm_finish_kernel)
+  constexpr int NPI = kWave / LPR;
+  auto add = [](float4& a, const float4& x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; };
   float4 acc = r4_zero();
-  for (int k = 0; k < nc; ++k) {
-    const float4 x = p[static_cast<int64_t>(k) * LPR];
-    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+  int k = lane / LPR;
+  for (; k + 3 * NPI < nc; k += 4 * NPI) {
+    const float4 x0 = p[static_cast<int64_t>(k) * LPR], x1 = p[static_cast<int64_t>(k + NPI) * LPR];
+    const float4 x2 = p[static_cast<int64_t>(k + 2 * NPI) * LPR], x3 = p[static_cast<int64_t>(k + 3 * NPI) * LPR];
+    add(acc, x0); add(acc, x1); add(acc, x2); add(acc, x3);
+  }
+  for (; k < nc; k += NPI) add(acc, p[static_cast<int64_t>(k) * LPR]);
+#pragma unroll
+  for (int m = LPR; m < kWave; m <<= 1) {
+    const float4 o = make_float4(__shfl_xor(acc.x, m), __shfl_xor(acc.y, m), __shfl_xor(acc.z, m), __shfl_xor(acc.w, m));
+    add(acc, o);
   }
   route_epilogue<LPR, K>(acc, r, lane, e);
 }
