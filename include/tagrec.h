@@ -104,7 +104,9 @@ int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t 
  * consults the flags only while they cover less than 4/5 of the rows (decided on the device, no host read).
  *   rownorm_bwd_flags   : tagrec_rownorm_bwd_f32 + flags / count of its output rows (the head of the chain)
  *   spmm_normbwd_sparse : tagrec_spmm_normbwd_drop_f32 reading in_flags (may be NULL) and writing out_flags / out_count
- *                         (may be NULL)
+ *                         (may be NULL).  row_mask (may be NULL): rows whose byte is 0 are left alone -- for a caller
+ *                         who knows their result is zero (no flagged neighbour, and X_raw / inv_norm / dZ zero there, as
+ *                         after the row-restricted forward) and has zeroed those rows of G_out / out_flags itself
  *   spmm_axpy_sparse    : tagrec_spmm_axpy_f32 reading in_flags */
 int tagrec_rownorm_bwd_flags_f32(const float* X_raw, const float* inv_norm, const float* dZ, int64_t lddz,
                                  float d_scale, float* dX, int accumulate, int64_t n_rows, int D,
@@ -112,7 +114,7 @@ int tagrec_rownorm_bwd_flags_f32(const float* X_raw, const float* inv_norm, cons
 int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                    const unsigned* in_count, const float* X_raw, const float* inv_norm,
                                    const float* dZ, float d_scale, float drop_p, uint64_t seed, float* G_out,
-                                   uint8_t* out_flags, unsigned* out_count, int D, void* stream);
+                                   uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask, int D, void* stream);
 int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                 const unsigned* in_count, const float* B, float b_scale, float* G_out, int D,
                                 void* stream);

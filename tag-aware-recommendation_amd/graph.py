@@ -312,13 +312,20 @@ class Graph:
                    _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), _lib.ptr(g_out), D, _lib.stream_ptr())
 
     def spmm_normbwd_sparse(self, g_in, in_flags, in_count, x_raw, inv_norm, dz, d_scale, g_out, out_flags, out_count,
-                            drop_p=0.0, seed=0):
+                            drop_p=0.0, seed=0, row_mask=None):
         """`spmm_normbwd` on a row-sparse g_in: rows whose in_flags byte is 0 are not gathered (same result); writes the
-        flags / count of its own output when out_flags is given."""
+        flags / count of its own output when out_flags is given.  row_mask: rows whose byte is 0 are not touched at all
+        (the caller knows their result is zero and has zeroed g_out / out_flags there)."""
         D = self._chk_x(g_in, self.shape[1], "spmm_normbwd g_in")
-        self._call("spmm_normbwd", _lib.load().tagrec_spmm_normbwd_sparse_f32, self._h, _lib.ptr(g_in), _lib.ptr(in_flags),
+        if row_mask is not None:
+            _lib.require_gpu_tensor(row_mask, torch.uint8, "row_mask")
+            if row_mask.numel() != self.shape[0]:
+                raise _lib.TagrecError("spmm_normbwd_sparse: row_mask must have one byte per row")
+        self._call("spmm_normbwd_rows" if row_mask is not None else "spmm_normbwd", _lib.load().tagrec_spmm_normbwd_sparse_f32,
+                   self._h, _lib.ptr(g_in), _lib.ptr(in_flags),
                    _lib.ptr(in_count), _lib.ptr(x_raw), _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), float(drop_p),
-                   int(seed), _lib.ptr(g_out), _lib.ptr(out_flags), _lib.ptr(out_count), D, _lib.stream_ptr())
+                   int(seed), _lib.ptr(g_out), _lib.ptr(out_flags), _lib.ptr(out_count), _lib.ptr(row_mask), D,
+                   _lib.stream_ptr())
 
     def spmm_axpy_sparse(self, g_in, in_flags, in_count, b, b_scale, g_out):
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")

@@ -24,7 +24,7 @@ def _layer_seed(seed, k):
     return (int(seed) * 64 + k) & 0xFFFFFFFFFFFFFFFF
 
 
-def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None):
+def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None, masks_out=None):
     """x0 -> (out, raws, invs): out = mean(x0, z1..zL), raws[k] = dropout(A raws[k-1]) (un-normalised),
     invs[k][r] = 1/max(||raws[k][r]||, 1e-12).  One fused kernel per layer.  drops[k] > 0 = message dropout of
     layer k's product (lightgcn.py:56), drawn inside the kernel from (seed, layer, element).
@@ -32,7 +32,8 @@ def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None):
     loss_rows (int64 node ids): `out` will be read at these rows only (the batch rows of the BPR loss).  Then the last
     layer is computed on them alone and the layer below it on their neighbours (anything further down reaches nearly
     every node through the popular items, so it runs in full); the rows left out stay zero in raws / invs and are
-    never read with a non-zero gradient in the backward pass.  Needs a square graph and a vector-kernel width."""
+    never read with a non-zero gradient in the backward pass.  Needs a square graph and a vector-kernel width.
+    masks_out (dict): receives {layer: row mask} of the restricted layers, for `propagate_backward`."""
     s = 1.0 / (n_layer + 1)
     out = x0 * s
     raws, invs = [], []
@@ -45,6 +46,8 @@ def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None):
         masks[n_layer - 1] = top
         if n_layer >= 2:
             masks[n_layer - 2] = graph.mark_rows(loss_rows, torch.zeros_like(top))
+    if masks_out is not None:
+        masks_out.update(masks)
     for k in range(n_layer):
         if k in masks:
             y = torch.zeros_like(x0)
@@ -63,11 +66,14 @@ def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None):
     return out, raws, invs
 
 
-def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0):
+def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0, masks=None):
     """Gradient of `propagate_forward` w.r.t. x0 given d_out (dense [N,D]).
     G^L = nb(X^L);  G^k = A^T G^(k+1) + nb(X^k);  G^0 = A^T G^1 + s*d_out,  nb = normalise-backward of s*d_out.
     With dropout each G^k (k >= 1) is multiplied by layer k's mask / (1 - p) before it travels on (it is the gradient
-    w.r.t. the product the mask was applied to)."""
+    w.r.t. the product the mask was applied to).
+    masks = the row masks of a restricted forward (`propagate_forward(masks_out=...)`): a layer that was computed on
+    masks[k] only has raws[k] = invs[k] = 0 elsewhere, and the gradient arriving from the layer above lives on rows
+    whose neighbours all lie inside masks[k] -- so G^k is exactly zero outside masks[k] and those rows are not visited."""
     L = len(raws)
     s = 1.0 / (L + 1)
     if L == 0:
@@ -92,10 +98,13 @@ def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0):
         H.message_drop(g, drops[L - 1], _layer_seed(seed, L - 1), out=g)     # flags stay a superset of the non-zero rows
     cur = 0
     for k in range(L - 2, -1, -1):
-        gn = torch.empty_like(d_out)
+        mask = masks.get(k) if (masks and sparse and (k + 1) in masks) else None
+        gn = torch.empty_like(d_out) if mask is None else torch.zeros_like(d_out)
         if sparse:
+            if mask is not None:
+                flags[1 - cur].zero_()
             graph_t.spmm_normbwd_sparse(g, flags[cur], counts[cur:cur + 1], raws[k], invs[k], d_out, s, gn, flags[1 - cur],
-                                        counts[1 - cur:2 - cur], drops[k] if drops else 0.0, _layer_seed(seed, k))
+                                        counts[1 - cur:2 - cur], drops[k] if drops else 0.0, _layer_seed(seed, k), mask)
             cur = 1 - cur
         else:
             graph_t.spmm_normbwd(g, raws[k], invs[k], d_out, s, gn, drops[k] if drops else 0.0, _layer_seed(seed, k))
@@ -131,7 +140,8 @@ class _PropagateBprLoss(torch.autograd.Function):
         loss_rows = None
         if restrict:                     # the loss reads `out` at the batch rows only: users, and items offset by n_user
             loss_rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user])
-        out, raws, invs = propagate_forward(graph, x0, n_layer, drops, seed, loss_rows)
+        ctx.masks = {}
+        out, raws, invs = propagate_forward(graph, x0, n_layer, drops, seed, loss_rows, ctx.masks)
         ctx.drops, ctx.seed = drops, seed
         B, D = trip.shape[0], x0.shape[1]
         coef = torch.empty(B, dtype=torch.float32, device=x0.device)
@@ -160,7 +170,7 @@ class _PropagateBprLoss(torch.autograd.Function):
                                           _lib.ptr(ctx.coef), _lib.ptr(g), 1.0,
                                           _lib.ptr(d_out[:nu]), _lib.ptr(d_out[nu:nu + ni]), null, null,
                                           _lib.stream_ptr()), "bpr_bwd")
-        g0 = propagate_backward(ctx.graph.transpose(), d_out, ctx.raws, ctx.invs, ctx.drops, ctx.seed)
+        g0 = propagate_backward(ctx.graph.transpose(), d_out, ctx.raws, ctx.invs, ctx.drops, ctx.seed, ctx.masks)
         # L2 term on the ego rows: added after the propagation hop has written g0
         if ctx.reg_active:
             Ue, Ie = x0[:nu], x0[nu:nu + ni]
