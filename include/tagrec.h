@@ -136,7 +136,8 @@ int tagrec_spmm_ss_rows_f32(const tagrec_graph* g, const float* X, float* Y, flo
 int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                        const unsigned* in_count, const float* X_raw, const float* inv_norm,
                                        const float* dZ, const float* dot, float d_scale, float* G_out,
-                                       uint8_t* out_flags, unsigned* out_count, int D, void* stream);
+                                       uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask, int D,
+                                       void* stream);
 /* row_flags[r] = (row r of X [n_rows, D] holds a non-zero), *count = number of such rows: for operands whose producer
  * does not write flags itself (the NGCF backward's dN). */
 int tagrec_row_flags_f32(const float* X, int64_t n_rows, int D, uint8_t* row_flags, unsigned* count, void* stream);

@@ -507,7 +507,7 @@ int launch_vec(const tagrec_graph* g, const float* X, const EpiArgs& e, hipStrea
     lv.slab = g->slab;
     lv.chunk_blocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
   }
-  if constexpr (EPI == EPI_NONE || EPI == EPI_NORM_ACC || EPI == EPI_SS || EPI == EPI_NORMBWD) {   // these can be row-masked
+  if constexpr (EPI == EPI_NONE || EPI == EPI_NORM_ACC || EPI == EPI_SS || EPI == EPI_NORMBWD || EPI == EPI_NORMBWD_DOT) {   // can be row-masked
     if (e.row_mask) {
       spmm_rows_kernel<LPR, EPI, true><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
       TAGREC_LAUNCH_CHECK();
@@ -656,13 +656,14 @@ extern "C" int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G
 extern "C" int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                                   const unsigned* in_count, const float* X_raw, const float* inv_norm,
                                                   const float* dZ, const float* dot, float d_scale, float* G_out,
-                                                  uint8_t* out_flags, unsigned* out_count, int D, void* stream) {
+                                                  uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask, int D,
+                                                  void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr && dot != nullptr,
                  "spmm_normbwd_dot_sparse: null X_raw, inv_norm, dZ or dot");
   TAGREC_REQUIRE(in_flags != nullptr && in_count != nullptr, "spmm_normbwd_dot_sparse: null in_flags or in_count");
   TAGREC_REQUIRE((out_flags == nullptr) == (out_count == nullptr), "spmm_normbwd_dot_sparse: out_flags and out_count go together");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_normbwd_dot_sparse: D must be 8 .. 256, a power of two");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, in_flags, in_count, out_flags, nullptr};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, in_flags, in_count, out_flags, row_mask};
   int rc = launch_spmm<EPI_NORMBWD_DOT>(g, G_in, e, D, stream, "spmm_normbwd_dot_sparse");
   if (rc != TAGREC_OK || !out_flags) return rc;
   return count_flags(out_flags, g->n_rows, out_count, static_cast<hipStream_t>(stream));

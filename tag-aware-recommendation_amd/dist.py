@@ -116,12 +116,18 @@ class HipOps:
                                                     _lib.stream_ptr()), "row_flags")
         return flags, count
 
-    def spmm_normbwd_dot_sparse(self, g, g_in, fl, x_raw, inv, dz, dot, s, out):
-        out_flags = torch.empty(out.shape[0], dtype=torch.uint8, device=out.device)
+    def spmm_normbwd_dot_sparse(self, g, g_in, fl, x_raw, inv, dz, dot, s, out, row_mask=None):
+        """row_mask: only these rows can be non-zero (see lightgcn.propagate_backward); the others are zero-filled here
+        and not visited by the kernel."""
+        if row_mask is None:
+            out_flags = torch.empty(out.shape[0], dtype=torch.uint8, device=out.device)
+        else:
+            out_flags = torch.zeros(out.shape[0], dtype=torch.uint8, device=out.device)
+            out.zero_()
         out_count = torch.zeros(1, dtype=torch.int32, device=out.device)
         g._call("spmm_normbwd_dot", _lib.load().tagrec_spmm_normbwd_dot_sparse_f32, g.handle, _lib.ptr(g_in), _lib.ptr(fl[0]),
                 _lib.ptr(fl[1]), _lib.ptr(x_raw), _lib.ptr(inv), _lib.ptr(dz), _lib.ptr(dot), float(s), _lib.ptr(out),
-                _lib.ptr(out_flags), _lib.ptr(out_count), g_in.shape[1], _lib.stream_ptr())
+                _lib.ptr(out_flags), _lib.ptr(out_count), _lib.ptr(row_mask), g_in.shape[1], _lib.stream_ptr())
         return out_flags, out_count
 
     def spmm_axpy_sparse(self, g, g_in, fl, b, s, out):
@@ -333,7 +339,7 @@ class _FeatureShardedLoss(torch.autograd.Function):
             loss = torch.nn.functional.softplus(xd).mean()
             coef = torch.where(xd > 20.0, torch.ones_like(xd), torch.sigmoid(xd))
         res = torch.stack([loss, dots[:, 2].sum() / B])
-        ctx.m, ctx.raws, ctx.invs = m, raws, invs
+        ctx.m, ctx.raws, ctx.invs, ctx.masks = m, raws, invs, masks
         ctx.out, ctx.x0, ctx.trip, ctx.coef = out, x0, trip, coef.contiguous()
         return res
 
@@ -361,7 +367,9 @@ class _FeatureShardedLoss(torch.autograd.Function):
             for k in range(L - 2, -1, -1):
                 gn = torch.empty_like(d_out)
                 if sparse:
-                    fl = m.ops.spmm_normbwd_dot_sparse(m.graph, gl, fl, raws[k], invs[k], d_out, dots[k], s, gn)
+                    # below the top layer of a restricted forward the result is exactly zero outside that layer's row mask
+                    mask = ctx.masks.get(k) if (k + 1) in ctx.masks else None
+                    fl = m.ops.spmm_normbwd_dot_sparse(m.graph, gl, fl, raws[k], invs[k], d_out, dots[k], s, gn, mask)
                 else:
                     m.ops.spmm_normbwd_dot(m.graph, gl, raws[k], invs[k], d_out, dots[k], s, gn)
                 gl = gn
