@@ -116,8 +116,8 @@ int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float* G_in, con
                                    const float* dZ, float d_scale, float drop_p, uint64_t seed, float* G_out,
                                    uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask, int D, void* stream);
 int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
-                                const unsigned* in_count, const float* B, float b_scale, float* G_out, int D,
-                                void* stream);
+                                const unsigned* in_count, const float* B, float b_scale, float* G_out,
+                                const uint8_t* row_mask /* may be NULL; as in spmm_normbwd_sparse */, int D, void* stream);
 /* Forward layer on a SUBSET of the output rows.  The loss reads the propagated table at the batch rows only
  * (model/lightgcn.py:71-75), so the last layer is needed on those rows and the layer below it on their neighbours.
  *   graph_mark_rows   : flags[c] = 1 for every column index stored in the listed rows and for the rows themselves

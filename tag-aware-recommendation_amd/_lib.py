@@ -90,7 +90,7 @@ _SIGNATURES = {
                                      c_void_p, c_void_p],
     "tagrec_spmm_normbwd_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                        ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
-    "tagrec_spmm_axpy_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p],
+    "tagrec_spmm_axpy_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_spmm_normbwd_dot_sparse_f32": [c_void_p] * 8 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_graph_mark_rows_u8": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_spmm_norm_acc_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, ctypes.c_uint64,

@@ -507,17 +507,15 @@ int launch_vec(const tagrec_graph* g, const float* X, const EpiArgs& e, hipStrea
     lv.slab = g->slab;
     lv.chunk_blocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
   }
-  if constexpr (EPI == EPI_NONE || EPI == EPI_NORM_ACC || EPI == EPI_SS || EPI == EPI_NORMBWD || EPI == EPI_NORMBWD_DOT) {   // can be row-masked
-    if (e.row_mask) {
-      spmm_rows_kernel<LPR, EPI, true><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
+  if (e.row_mask) {                       // rows whose mask byte is 0 are left alone (a separate instantiation)
+    spmm_rows_kernel<LPR, EPI, true><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
+    TAGREC_LAUNCH_CHECK();
+    if (g->n_long > 0) {
+      const unsigned fblocks = static_cast<unsigned>((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+      spmm_finish_kernel<LPR, EPI, true><<<fblocks, threads, 0, s>>>(gv, g->long_rows, g->long_base, g->n_long, g->slab, e);
       TAGREC_LAUNCH_CHECK();
-      if (g->n_long > 0) {
-        const unsigned fblocks = static_cast<unsigned>((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock);
-        spmm_finish_kernel<LPR, EPI, true><<<fblocks, threads, 0, s>>>(gv, g->long_rows, g->long_base, g->n_long, g->slab, e);
-        TAGREC_LAUNCH_CHECK();
-      }
-      return TAGREC_OK;
     }
+    return TAGREC_OK;
   }
   spmm_rows_kernel<LPR, EPI><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
   TAGREC_LAUNCH_CHECK();
@@ -645,11 +643,11 @@ extern "C" int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float
 }
 
 extern "C" int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
-                                           const unsigned* in_count, const float* B, float b_scale, float* G_out, int D,
-                                           void* stream) {
+                                           const unsigned* in_count, const float* B, float b_scale, float* G_out,
+                                           const uint8_t* row_mask, int D, void* stream) {
   TAGREC_REQUIRE(B != nullptr && in_flags != nullptr && in_count != nullptr, "spmm_axpy_sparse: null B, in_flags or in_count");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_sparse: D must be 8 .. 256, a power of two");
-  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, nullptr};
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, row_mask};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_sparse");
 }
 

@@ -327,10 +327,16 @@ class Graph:
                    int(seed), _lib.ptr(g_out), _lib.ptr(out_flags), _lib.ptr(out_count), _lib.ptr(row_mask), D,
                    _lib.stream_ptr())
 
-    def spmm_axpy_sparse(self, g_in, in_flags, in_count, b, b_scale, g_out):
+    def spmm_axpy_sparse(self, g_in, in_flags, in_count, b, b_scale, g_out, row_mask=None):
+        """row_mask: rows whose byte is 0 are not touched (the caller knows their result and has written it)."""
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")
-        self._call("spmm_axpy", _lib.load().tagrec_spmm_axpy_sparse_f32, self._h, _lib.ptr(g_in), _lib.ptr(in_flags),
-                   _lib.ptr(in_count), _lib.ptr(b), float(b_scale), _lib.ptr(g_out), D, _lib.stream_ptr())
+        if row_mask is not None:
+            _lib.require_gpu_tensor(row_mask, torch.uint8, "row_mask")
+            if row_mask.numel() != self.shape[0]:
+                raise _lib.TagrecError("spmm_axpy_sparse: row_mask must have one byte per row")
+        self._call("spmm_axpy_rows" if row_mask is not None else "spmm_axpy", _lib.load().tagrec_spmm_axpy_sparse_f32, self._h,
+                   _lib.ptr(g_in), _lib.ptr(in_flags), _lib.ptr(in_count), _lib.ptr(b), float(b_scale), _lib.ptr(g_out),
+                   _lib.ptr(row_mask), D, _lib.stream_ptr())
 
     def spmm_axpy(self, g_in, b, b_scale, g_out):
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")

@@ -90,7 +90,7 @@ def propagate_forward(graph, x0, wps, dims, loss_rows=None):
             zc = torch.empty(rows.numel(), d, dtype=torch.float32, device=x0.device)
             dense_forward(nc, xc, w1p, w2p, xpc, invc, zc, d)
             out[:, off:off + d].index_copy_(0, rows, zc)          # the other rows of this slot are never read
-            saved.append(("rows", rows, masks[k], xc, nc, xpc, invc, w1p, w2p))
+            saved.append(("rows", rows, masks[k], masks.get(k - 1), xc, nc, xpc, invc, w1p, w2p))
             break
         xp = torch.empty(n, dims[k + 1], dtype=torch.float32, device=x0.device)
         inv = torch.empty(n, dtype=torch.float32, device=x0.device)
@@ -111,7 +111,7 @@ def propagate_backward(graph_t, d_out, saved, dims):
     dx_next = None
     for k in range(len(saved) - 1, -1, -1):
         if isinstance(saved[k][0], str):                       # the top layer of a restricted forward pass: batch rows only
-            _, rows, mask, xc, nc, xpc, invc, w1p, w2p = saved[k]
+            _, rows, mask, reach, xc, nc, xpc, invc, w1p, w2p = saved[k]
             d = dims[k + 1]
             dzc = d_out[:, offs[k + 1]:offs[k + 1] + d].index_select(0, rows)
             d_nei_c, d_xd_c, dw1, dw2 = dense_backward(None, nc, xc, w1p, w2p, norm=(xpc, invc, dzc, d))
@@ -120,8 +120,10 @@ def propagate_backward(graph_t, d_out, saved, dims):
             d_nei = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_copy_(0, rows, d_nei_c)
             d_xd = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_copy_(0, rows, d_xd_c)
             count = torch.full((1,), rows.numel(), dtype=torch.int32, device=xc.device)
-            dx = torch.empty(n, din, dtype=torch.float32, device=xc.device)
-            graph_t.spmm_axpy_sparse(d_nei, mask, count, d_xd, 1.0, dx)
+            # d_nei and d_xd live on the batch rows, so dx is zero outside `reach` = those rows and their neighbours (the
+            # mask the layer below was computed on): only they are visited
+            dx = (torch.empty if reach is None else torch.zeros)(n, din, dtype=torch.float32, device=xc.device)
+            graph_t.spmm_axpy_sparse(d_nei, mask, count, d_xd, 1.0, dx, reach)
             dx_next = dx
             continue
         x, nei, xp, inv, w1p, w2p = saved[k]
