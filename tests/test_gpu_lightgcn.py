@@ -406,3 +406,39 @@ def test_restricted_forward_equals_full_forward_step(n_layer):
     np.testing.assert_allclose(l1, l0, rtol=1e-6)
     scale = float(g0.abs().max())
     np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-4, atol=1e-6 * scale)
+
+
+def test_feature_sharded_restricted_step_equals_single_gpu_model():
+    """FeatureShardedLightGCN (one rank, real kernels) on a graph large enough for its restricted forward and the
+    row-masked backward hop (B * 48 <= N): loss parts and table gradient of the single-GPU model, itself run with every
+    layer on all rows."""
+    import os
+    import torch.distributed as dist
+    from tagrec_amd import dist as TD
+    ds = T.synth.make_bipartite_device(30_000, 20_000, 1_500_000, seed=3, device=DEV)
+    e = ds.edge_index["train"]
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 30_000, 20_000, "bi_norm")
+    cfg = T.get_config("lightgcn", use_tag=False, dim_latent=64, dim_layer_list=[64] * 3, device=DEV, train_batch=128, reg=1e-3)
+    torch.manual_seed(2)
+    m = T.LightGCN(ds, config=cfg, graph=T.Graph(rp, col, val, (n, n), symmetric=True))
+    m.train()
+    m.restrict_forward = False
+    batch = T.BPR_training_data(ds, config=cfg, seed=1).all_train_data[:128]
+    assert batch.shape[0] * 48 <= n
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29574")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        sm = TD.FeatureShardedLightGCN(ds, cfg, rp, col, val, n)
+        assert sm.ops.restrict_forward and sm.ops.sparse_backward
+        with torch.no_grad():
+            sm.table.copy_(m.table)
+        l1, l2 = m.loss(batch), sm.loss(batch)
+        np.testing.assert_allclose([float(v) for v in l2], [float(v) for v in l1], rtol=2e-6)
+        sum(l1).backward(); sum(l2).backward()
+        g0, g1 = m.table.grad, sm.table.grad
+        scale = float(g0.abs().max())
+        np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale)
+    finally:
+        dist.destroy_process_group()
