@@ -442,3 +442,19 @@ def test_feature_sharded_restricted_step_equals_single_gpu_model():
         np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("D", [8, 64, 256, 20])
+def test_row_flags_kernel(D):
+    """`tagrec_row_flags_f32`: flag = row holds a non-zero, count = number of flagged rows; row count not a multiple of
+    the rows a block covers."""
+    from tagrec_amd import dist as TD
+    n = 10_007
+    gen = torch.Generator().manual_seed(D)
+    x = torch.zeros(n, D)
+    rows = torch.randperm(n, generator=gen)[:777]
+    x[rows, torch.randint(0, D, (777,), generator=gen)] = 1.5
+    x[n - 1, D - 1] = -0.0                                   # a negative zero is still a zero
+    flags, count = TD.HipOps().row_flags(x.to(DEV))
+    want = (x != 0).any(dim=1)
+    assert torch.equal(flags.cpu().bool(), want) and int(count) == int(want.sum()) == 777
