@@ -10,11 +10,16 @@ Adam lr 0.01, train_batch 512 (the reference's default, utility/utils.py:24).  O
 BPR loss, backward, Adam.  Everything is resident in HBM before the timed region; triplets are
 sampled on the device beforehand (the reference also times its sampler separately).
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME graph and batch are split
-over the ranks (strong scaling).  Default `--parallel feature`: every rank holds D/N columns of the
-node table, Adam state and activations plus the whole CSR; only row norms, row dot products and the
-B triplet scores are all-reduced over RCCL.  `--parallel row`: rows are sharded and every layer
-all-gathers the shard outputs (the reference's split_adj_k folds, one per GPU).
+With N > 1 the SAME graph and batch are split over N ranks, one per GPU (strong scaling).  Launch either
+as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` or as plain
+`python bench.py --gpus N`: the latter starts the N ranks itself (fresh child processes; the parent
+never touches the GPU).  `--parallel row` (default from 4 ranks): the node table, Adam state and CSR
+rows are sharded by row range -- the reference's split_adj_k folds (adj.py:114-140,158-164), one per GPU
+-- and the step is the restricted one of the single-GPU model: block-wise pipelined all-gathers of the
+layers that need every row, the top layer in push form on the batch rows, flagged gradient tables
+(tagrec_amd/dist.py).  `--parallel feature` (default at 2 ranks, where one xGMI link
+would carry every exchange): every rank holds D/N columns of every row plus the whole CSR; only row
+norms, row dot products and the B triplet scores are all-reduced.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused forward layer
 (`spmm_rows_kernel<16, NORM_ACC>`): algorithmic bytes per launch (SURVEY.md 8d:
@@ -47,13 +52,18 @@ def parse():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--big-batch", type=int, default=786432, help="also report triplets/s at this batch (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed steps of the CPU baseline (after one warm-up step)")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded model even with one rank (exercises dist.py + RCCL init on one GPU)")
     ap.add_argument("--parallel", choices=["auto", "feature", "row"], default="auto",
-                    help="multi-GPU sharding of the node table: feature = columns (default when dim %% N == 0 and "
-                         "dim / N >= 8), row = row ranges with an all-gather per layer")
+                    help="multi-GPU sharding of the node table: row = row ranges (the reference's folds; default from 4 "
+                         "ranks), feature = columns (default at 2 ranks when dim / 2 >= 32)")
+    ap.add_argument("--chunks", type=int, default=0, help="row blocks per shard for the pipelined all-gathers (0 = default)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 and the ranks exchange "
+                         "through gloo (RCCL wants one device per rank); numbers from such a run are not scaling results")
     ap.add_argument("--model", choices=["lightgcn", "ngcf", "tgcn", "dgcf", "disengcn"], default="lightgcn",
                     help="lightgcn = C2 (headline); ngcf = C3 (same graph, D^-1 A + I, MFMA dense layers); "
                          "tgcn = C4 (tripartite, 1M/1M/2M nodes, D=128, k=25; use --steps 3 --warmup 1); "
@@ -65,40 +75,90 @@ def spmm_bytes(nnz, n_rows, D, epilogue_row_bytes):
     return nnz * (8 + 4 * D) + n_rows * (8 + 4 * D) + n_rows * epilogue_row_bytes
 
 
-def cpu_baseline(args, full_nnz):
-    """CPU oracle step time on a 1/8-scale C2-shaped graph (about 15 s of CPU work), scaled to the full graph by stored
-    entries."""
-    import tagrec_amd as T
-    from oracle import adj as oadj, models as om
-    frac = 8 if args.scale >= 0.5 else 1
-    nu = max(int(1_000_000 * args.scale) // frac, 1000)
-    ne = max(int(50_000_000 * args.scale) // frac, 20000)
-    # the GPU box gives one-GPU jobs a 16-core share of the host; more threads only oversubscribe it
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
-    torch.set_num_threads(cores)
-    ds = T.synth.make_bipartite_device(nu, nu, ne, seed=11, device="cpu")
-    e = ds.edge_index["train"]
-    rp, c, v, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], nu, nu)
-    A = om.csr_to_torch(oadj.CSR(rp.numpy(), c.numpy(), v.numpy(), (n, n)))
-    torch.manual_seed(2020)
-    tabs = [t.requires_grad_() for t in om.xavier_tables([(nu, args.dim), (nu, args.dim)], 2020)]
-    opt = torch.optim.Adam(tabs, lr=0.01)
-    g = torch.Generator().manual_seed(5)
-    n_warm, n_timed = 1, 3
-    pick = torch.randint(0, e.shape[0], ((n_warm + n_timed) * args.batch,), generator=g)
-    tri = torch.stack([e[pick, 0], e[pick, 1], torch.randint(0, nu, (pick.numel(),), generator=g)], 1)
-    batches = [tri[k * args.batch:(k + 1) * args.batch] for k in range(n_warm + n_timed)]
-    fn = lambda b: om.lightgcn_loss(tabs, A, args.layers, b, 0.0, "softplus")
-    om.adam_epoch(tabs, fn, batches[:n_warm], opt)
+def kernel_source_sha16():
+    """Identity of the SpMM kernel sources, so that counter data collected for another version is refused."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("spmm.hip", "graph.h", "common.h"):
+        with open(os.path.join(ROOT, "tag-aware-recommendation_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(model, D, kname):
+    """HBM-side bytes per launch of `kname` from the newest committed rocprofv3 PMC summary of this command
+    (profiles/rNN_pmc_<config>.json, written by tools/profile.sh + tools/pmc_summary.py: separate --pmc passes,
+    (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 note of MI355X_MICROARCH.md).  NOT measured in this run -- counters
+    need the profiler -- so the source is named, and data collected for other kernel sources is refused."""
+    import glob
+    tag = {"lightgcn": "c2_lightgcn", "ngcf": "c3_ngcf"}.get(model)
+    if tag is None or D != 64:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{tag}.json")))
+    if not files:
+        return None, "no committed PMC summary for this configuration"
+    with open(files[-1]) as f:
+        js = json.load(f)
+    rel = os.path.relpath(files[-1], ROOT)
+    sha = kernel_source_sha16()
+    if js.get("kernel_source_sha16") != sha:
+        return None, (f"refused: {rel} was collected for kernel sources {js.get('kernel_source_sha16', 'unrecorded')}, "
+                      f"this tree has {sha}; re-run tools/profile.sh")
+    k = js["kernels"].get(kname)
+    if k is None:
+        return None, f"refused: {rel} has no kernel named {kname}"
+    return k["traffic_bytes_per_launch"], (f"{rel}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `{js.get('command', '?')}`, "
+                                           f"collected {js.get('collected', '?')} at commit {js.get('head', '?')}, kernel sources {sha}; "
+                                           "not re-measured by this run")
+
+
+def _cpu_steps(om, model_kind, tabs, mats, A, layers, batches, n_warm):
+    params = tabs + mats
+    opt = torch.optim.Adam(params, lr=0.01)
+    if model_kind == "ngcf":
+        W = {k: m for k, m in zip(_ngcf_keys(layers), mats)}
+        fn = lambda b: om.ngcf_loss(tabs, W, A, layers, b, 0.0, "logsigmoid")
+    else:
+        fn = lambda b: om.lightgcn_loss(tabs, A, layers, b, 0.0, "softplus")
+    om.adam_epoch(params, fn, batches[:n_warm], opt)
     t0 = time.perf_counter()
-    om.adam_epoch(tabs, fn, batches[n_warm:], opt)
-    dt = (time.perf_counter() - t0) / n_timed
-    nnz_s = int(rp[-1])
-    scaled = dt * full_nnz / nnz_s
-    return {"value": args.batch / scaled, "unit": "triplets/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (torch {torch.__version__} CPU, {cores} threads), LightGCN L={args.layers} D={args.dim} "
-                      f"B={args.batch} on a {nu}x{nu} graph with nnz={nnz_s}: {dt * 1e3:.1f} ms/step measured over {n_timed} steps; "
-                      f"scaled by nnz ratio {full_nnz / nnz_s:.1f} to the full graph"}
+    om.adam_epoch(params, fn, batches[n_warm:], opt)
+    return (time.perf_counter() - t0) / (len(batches) - n_warm)
+
+
+def _ngcf_keys(layers):
+    return [f"{w}_{k}" for k in range(layers) for w in ("W1", "b1", "W2", "b2")]
+
+
+def cpu_baseline(args, model_kind, rp, col, val, n, nu, ni, epoch):
+    """The CPU oracle (oracle/models.py: torch.sparse.mm on a COO tensor built like the reference's sp2tensor, F.normalize,
+    softplus / logsigmoid, autograd, torch.optim.Adam -- checked op for op against the imported reference, tests/golden)
+    timed on THIS workload: the same graph the GPU leg just ran (its CSR copied to the host), the same batch size,
+    1 warm-up + `--cpu-steps` timed steps on the host cores of the box.  `extra_sample` repeats the round-1 figure
+    (a 1/8-scale graph scaled by stored entries) for comparison."""
+    from oracle import adj as oadj, models as om
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))   # the box gives a one-GPU job a 16-core share of the host
+    torch.set_num_threads(cores)
+    D, L, B = args.dim, args.layers, args.batch
+    n_warm, n_timed = 1, max(1, args.cpu_steps)
+    print(f"[bench] cpu_baseline: {model_kind} oracle on the full graph (nnz={int(rp[-1])}), {n_warm}+{n_timed} steps, "
+          f"{cores} threads ...", file=sys.stderr, flush=True)
+    A = om.csr_to_torch(oadj.CSR(rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(), (n, n)))
+    tabs = [t.requires_grad_() for t in om.xavier_tables([(nu, D), (ni, D)], 2020)]
+    mats = []
+    if model_kind == "ngcf":
+        for _ in range(L):
+            for shp in ((D, D), (1, D), (D, D), (1, D)):
+                t = torch.empty(*shp)
+                torch.nn.init.xavier_uniform_(t)
+                mats.append(t.requires_grad_())
+    batches = [epoch[k * B:(k + 1) * B].cpu() for k in range(n_warm + n_timed)]
+    dt = _cpu_steps(om, model_kind, tabs, mats, A, L, batches, n_warm)
+    name = "NGCF" if model_kind == "ngcf" else "LightGCN"
+    return {"value": B / dt, "unit": "triplets/s", "cores": cores, "kind": "port", "ms_per_step": dt * 1e3,
+            "sample": f"CPU oracle (torch {torch.__version__} CPU ops, {cores} threads), {name} L={L} D={D} B={B} on the FULL "
+                      f"workload graph ({nu} x {ni}, nnz={int(rp[-1])}): {dt:.2f} s/step measured over {n_timed} steps after "
+                      f"{n_warm} warm-up step; no scaling applied"}
 
 
 def bench_tgcn(args):
@@ -193,18 +253,69 @@ def bench_tgcn(args):
     print(json.dumps(out))
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N fresh rank processes (this parent has made no
+    GPU call and makes none), hand rank 0's JSON line through, return the worst exit code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()              # counts devices without initialising the GPU
+    if n_dev < args.gpus and not args.share_gpu:
+        print(json.dumps({"error": f"bench.py --gpus {args.gpus}: this machine exposes {n_dev} GPU(s); one rank per GPU is "
+                                   "required (RCCL).  For a functional rehearsal on fewer GPUs add --share-gpu "
+                                   "(ranks share cuda:0 and exchange through gloo).", "n_gpus": args.gpus}))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+def collective_probe(shape, dev, world, reps=5):
+    """ms of one all_gather_into_tensor of a [rows, D] block per rank and of one all_reduce of a [3, 1536, D] buffer
+    (the two exchange shapes of the row-sharded step), measured before the timed region."""
+    import torch.distributed as dist
+    rows, D = shape
+    x = torch.zeros(rows, D, device=dev)
+    full = torch.empty(rows * world, D, device=dev)
+    small = torch.zeros(3, 1536, D, device=dev)
+    out = {}
+    for name, fn in (("all_gather_block_ms", lambda: dist.all_gather_into_tensor(full, x)),
+                     ("all_reduce_batch_rows_ms", lambda: dist.all_reduce(small))):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t) / reps * 1e3
+    out["all_gather_block_bytes_in"] = rows * D * 4 * (world - 1)
+    return out
+
+
 def main():
     args = parse()
     if args.model == "tgcn":
         return bench_tgcn(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run with N ranks")
-        args.gpus = world
+    args.gpus = world
+    if args.share_gpu:
+        local = 0
     assert torch.cuda.is_available(), "bench.py needs a GPU (tagrec_amd has no CPU path)"
+    if local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} GPU(s) are visible "
+                 "(one rank per GPU; --share-gpu for a rehearsal)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import tagrec_amd as T
@@ -217,7 +328,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu and world > 1:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         from tagrec_amd import dist as TD
 
     nu = ni = max(int(1_000_000 * args.scale), 2000)
@@ -226,7 +340,10 @@ def main():
     cfg = T.get_config(args.model, use_tag=False, dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B)
     parallel = args.parallel
     if parallel == "auto":
-        parallel = "feature" if (D % world == 0 and D // world >= 8) else "row"
+        # 2 ranks share ONE xGMI link: a row partition would push ~3.5 tables per step through it, the column partition
+        # exchanges 50 MB and keeps 128-byte rows at D/2 >= 32.  From 4 ranks the row partition (the reference's folds)
+        # spreads the same bytes over 3 / 7 links and its per-rank product keeps full-width rows.
+        parallel = "feature" if (world == 2 and D % 2 == 0 and D // 2 >= 32) else "row"
     Dl = D // world if (sharded and parallel == "feature") else D
     if args.model != "lightgcn" and world > 1:
         sys.exit(f"bench.py: the sharded path covers LightGCN (C2/C5); run --model {args.model} on one GPU")
@@ -250,7 +367,7 @@ def main():
         if parallel == "feature":
             model = TD.FeatureShardedLightGCN(ds, cfg, rp, col, val, n)
         else:
-            model = TD.ShardedLightGCN(ds, cfg, rp, col, val, n)
+            model = TD.ShardedLightGCN(ds, cfg, rp, col, val, n, n_chunks=args.chunks or None)
         timed_graph = model.graph
         del rp, col, val
     opt = T.Adam(model.parameters(), lr=cfg["lr"])
@@ -293,15 +410,36 @@ def main():
     W, K = args.warmup, args.steps
     batches = [epoch[k * B:(k + 1) * B] for k in range(W + K)]
     run_steps(batches[:W])
-    timed_graph.timing = {}
+    row_sharded = sharded and parallel == "row"
+    probe = collective_probe((model.part.rc, D), dev, world) if (row_sharded and world > 1) else None
+    # per-kernel HIP events on the launch stream; a row shard is walked in row blocks, one handle (and event list) each
+    timed_graphs = model.graph_chunks if row_sharded else [timed_graph]
+    for g_ in timed_graphs:
+        g_.timing = {}
+    if row_sharded:
+        model.timing, model.comm_bytes = {}, 0
     dt, last = timed(batches[W:])
-    kernel_ms = timed_graph.timing_ms()
-    timed_graph.timing = None
+    per_block = [g_.timing_ms() for g_ in timed_graphs]
+    kernel_ms = {k: [sum(v) for v in zip(*[pb.get(k, []) for pb in per_block])] for k in per_block[0]}
+    for g_ in timed_graphs:
+        g_.timing = None
     loss_val = [float(x) for x in last]
+    comm = None
+    if row_sharded:
+        waits = model.timing_ms()
+        model.timing = None
+        comm = {"world_size_seen_by_torch_distributed": dist.get_world_size(), "backend": dist.get_backend(),
+                "row_blocks_per_shard": model.part.n_chunks, "rows_per_rank": model.part.per,
+                "bytes_received_per_rank_per_step": model.comm_bytes / K,
+                "compute_stream_wait_ms_per_step": {k: sum(v) / K for k, v in waits.items()},
+                "collectives_per_step": {k: len(v) / K for k, v in waits.items()},
+                "probe": probe}
 
     extra = {"graph_build_s": round(t_build, 2), "epoch_sampling_s": round(t_sample, 3),
              "epoch_triplets": int(epoch.shape[0]), "last_loss": loss_val,
              "edge_layers_per_s": nnz * L * 2 * K / dt}
+    if comm is not None:
+        extra["collectives"] = comm
     if args.model == "lightgcn" and not sharded and getattr(model, "restrict_forward", False):
         # the same step with every forward layer computed on ALL rows (the timed step above computes the top two
         # layers only on the rows the batch's loss depends on -- same loss and gradients)
@@ -339,28 +477,34 @@ def main():
         per_row = 8 + 8 * D + 8 * KF + (4 * D if args.model == "disengcn" else 0)
         alg = local_nnz * (4 + 4 * KF + 4 * D) + n_local_rows * per_row
     roof = None
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_c2_lightgcn.json")
-    if world == 1 and args.scale == 1.0 and D == 64 and args.model == "lightgcn" and os.path.exists(pmc_path):
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
-        # ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction; see profiles/README.md)
-        with open(pmc_path) as f:
-            ks = json.load(f)["kernels"]
-            k = ks.get("spmm_rows_kernel<16, 1, false>") or ks.get("spmm_rows_kernel<16, 1>")
-            traffic = k["traffic_bytes_per_launch"]
+    traffic, traffic_source = None, None
+    epi_name = "SS" if dom == "spmm_ss" else ("NORM_ACC" if args.model == "lightgcn" else "NONE")
+    epi_id = {"NONE": 0, "NORM_ACC": 1, "SS": 4}[epi_name]
+    prof_kname = f"spmm_rows_kernel<{Dl // 4}, {epi_id}, false>"
+    if world == 1 and args.scale == 1.0 and not routed:
+        traffic, traffic_source = committed_traffic(args.model, D, prof_kname)
     if fwd:
         ms = sum(fwd) / len(fwd)
         ach = alg / (ms * 1e-3) / 1e9
-        epi_name = "SS" if dom == "spmm_ss" else ("NORM_ACC" if args.model == "lightgcn" else "NONE")
         kname = f"route_spmm_kernel<{D // 4}, {KF}>" if routed else f"spmm_rows_kernel<{Dl // 4}, {epi_name}>"
+        # compulsory bytes: every array of the launch touched exactly once (CSR, gathered table, outputs, accumulator
+        # read-modify-write) -- what a perfect cache would leave for HBM
+        comp = local_nnz * 8 + (n_local_rows + 1) * 8 + timed_graph.shape[1] * Dl * 4 + n_local_rows * Dl * 4
+        comp += {"NORM_ACC": n_local_rows * (8 * Dl + 4), "SS": n_local_rows * 4, "NONE": 0}[epi_name]
         roof = {"bound": "hbm", "kernel": kname + " (+ long-row finish)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "mean_launch_ms": ms, "launches_timed": len(fwd),
+                "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": alg, "compulsory_bytes": comp,
+                "mean_launch_ms": ms, "launches_timed": len(fwd),
                 "other_kernels_ms": {k: sum(v) / len(v) for k, v in kernel_ms.items() if k != dom}}
         if traffic:
-            # the algorithmic figure credits every gathered row as an HBM read; rows served by L2 make the counted
-            # traffic smaller, which is how `frac` can touch 1.0 -- this is the rate of the bytes that did cross the fabric
-            roof["traffic_frac"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # rate of the bytes that did cross the L2 <-> fabric boundary (HBM + Infinity Cache), from the PMC passes
+            roof["frac_counter"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["refetch_factor"] = traffic / comp
+        if roof["frac"] > 1.0:
+            roof["note"] = ("frac > 1: `achieved` bills every gathered row to HBM (SURVEY.md 8d, no cache credit) while part "
+                            "of them is served by L2 / Infinity Cache; the counted fabric-side rate is frac_counter, and "
+                            "traffic / compulsory_bytes (refetch_factor) is the headroom a better row order could remove")
         if args.model == "lightgcn":
             # nominal traffic of a step that touches every row in every layer, for reference only: the
             # timed step reads less (rows the loss does not depend on / rows whose gradient is zero are not touched)
@@ -386,10 +530,12 @@ def main():
                                   "backward products do not fetch operand rows that are exactly zero "
                                   "(extra.ms_per_step_all_rows_forward = every forward layer on all rows)"},
                "roofline": roof, "extra": extra}
-        if not args.no_cpu and world == 1 and args.model == "lightgcn":
-            out["cpu_baseline"] = cpu_baseline(args, nnz)
+        if not args.no_cpu and world == 1 and args.model in ("lightgcn", "ngcf") and not sharded:
+            out["cpu_baseline"] = cpu_baseline(args, args.model, rp, col, val, n, nu, ni, epoch)
         else:
-            out["cpu_baseline"] = None
+            out["cpu_baseline"] = ("not run (--no-cpu)" if args.no_cpu else
+                                   "not run (timed on rank 0 of the 1-GPU configuration only)" if world > 1 or sharded else
+                                   "not run (no CPU oracle leg for this model in bench.py)")
         print(json.dumps(out))
     if sharded:
         dist.barrier()

@@ -14,7 +14,12 @@
  *   - return value: 0 = TAGREC_OK, negative = TAGREC_E_*; the message for the last
  *     failing call of the calling thread is tagrec_last_error().  No C++ exception
  *     crosses the ABI.
- *   - a handle may be used from one thread at a time; distinct handles are independent.
+ *   - a handle may be used from one thread AND one stream at a time (a graph handle owns the
+ *     partial-sum scratch of the launch in flight; launches on one stream are ordered, two
+ *     streams sharing a handle would race on it); distinct handles are independent.
+ *   - no entry point that takes a `stream` allocates or frees device memory: scratch is
+ *     either allocated when a handle is created or passed in by the caller (the
+ *     `*_workspace` size queries), so every such call may be captured in a HIP graph.
  *   - D (row width) must be a multiple of 4 and rows 16-byte aligned for the vector
  *     kernels; other widths take a scalar kernel (correct, slower).
  */
@@ -49,7 +54,8 @@ int tagrec_device_info(int* n_cu, int* wave_size, char* arch, int arch_len);
  * model/help/adj.py:38-46 `creat_adj` (+ :144-150 `sp2tensor`).  The arrays are BORROWED:
  * they must outlive the handle.  Creation scans the row lengths once (synchronises the
  * stream) and splits rows longer than 1024 entries into 512-entry chunks that are
- * reduced in a fixed order, so results do not depend on scheduling. */
+ * reduced in a fixed order, so results do not depend on scheduling.  The partial-sum
+ * scratch of those chunks (256 floats per chunk) is allocated here, once. */
 int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz,
                         const int64_t* rowptr, const int32_t* colidx, const float* vals, void* stream);
 /* A second matrix over the SAME row pointer (same rows, same entries per row) with its own column indices / values,
@@ -125,6 +131,8 @@ int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const 
  *   spmm_norm_acc_rows: tagrec_spmm_norm_acc_drop_f32 for the rows with row_mask[r] != 0; the other rows of Y_raw,
  *                       inv_norm and acc are left untouched */
 int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, uint8_t* flags, void* stream);
+/* the same for a rectangular matrix: flags (uint8 [n_cols]) of the columns stored in the listed rows, rows not marked */
+int tagrec_graph_mark_cols_u8(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, uint8_t* flags, void* stream);
 int tagrec_spmm_norm_acc_rows_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
                                   float* acc, float acc_scale, const uint8_t* row_mask, float drop_p,
                                   uint64_t seed, int D, void* stream);
@@ -132,6 +140,13 @@ int tagrec_spmm_norm_acc_rows_f32(const tagrec_graph* g, const float* X, float* 
 int tagrec_spmm_rows_f32(const tagrec_graph* g, const float* X, float* Y, const uint8_t* row_mask, int D, void* stream);
 int tagrec_spmm_ss_rows_f32(const tagrec_graph* g, const float* X, float* Y, float* ss, const uint8_t* row_mask, int D,
                             void* stream);
+/* The plain product on a short LIST of rows with a compact result: Y[k, :] = (A @ X)[rows[k], :], k < n_listed
+ * (rows int64, may repeat; rows[k] is NOT range-checked on the device -- the caller guarantees 0 <= rows[k] < n_rows).
+ * One block per listed row, fixed summation order.  With A = the column slice A[:, rows_g] of a row-sharded table
+ * this is rank g's share of the top layer at the batch rows (the 1-D fold partition of adj.py:114-140,158-164 turned
+ * into push form where the output is 3 B rows); the shares are summed by an all-reduce of [3 B, D]. */
+int tagrec_spmm_listed_f32(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, const float* X, float* Y,
+                           int D, void* stream);
 /* tagrec_spmm_normbwd_dot_f32 (column-sharded tables) on a row-sparse G_in */
 int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                        const unsigned* in_count, const float* X_raw, const float* inv_norm,

@@ -93,10 +93,12 @@ _SIGNATURES = {
     "tagrec_spmm_axpy_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_spmm_normbwd_dot_sparse_f32": [c_void_p] * 8 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_graph_mark_rows_u8": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+    "tagrec_graph_mark_cols_u8": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_spmm_norm_acc_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, ctypes.c_uint64,
                                       c_int, c_void_p],
     "tagrec_spmm_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_spmm_ss_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_spmm_listed_f32": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_row_flags_f32": [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
     "tagrec_eval_topk_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                              c_void_p, c_void_p],

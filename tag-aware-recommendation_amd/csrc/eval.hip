@@ -48,8 +48,11 @@ __global__ __launch_bounds__(kEvalThreads) void eval_topk_kernel(const float* __
     ub[s] = t.x; ub[s + 1] = t.y; ub[s + 2] = t.z; ub[s + 3] = t.w;
   }
   const int64_t tlo = uok ? train_ptr[user] : 0, thi = uok ? train_ptr[user + 1] : 0;
-  float* my_sc = sh_sc + uslot * K;
-  int* my_id = sh_id + uslot * K;
+  // The four lanes q = 0..3 of a user slot share its list and take turns (wave_barrier below).  That intrinsic orders
+  // execution, not memory, so the list is accessed through volatile pointers: every threshold read and every insertion
+  // goes to LDS and sees what the previous lane wrote.
+  volatile float* my_sc = sh_sc + uslot * K;
+  volatile int* my_id = sh_id + uslot * K;
   for (int64_t item0 = 0; item0 < n_item; item0 += 16) {
     // A-operand: row m = r is item item0 + r; k-slot q covers features q*DS .. q*DS+DS-1 (same split as ub)
     const int64_t it = item0 + r;
@@ -86,13 +89,21 @@ __global__ __launch_bounds__(kEvalThreads) void eval_topk_kernel(const float* __
             }
             if (!(lo < thi && train_items[lo] == item)) {
               int p = K - 1;
-              while (p > 0 && my_sc[p - 1] < sg[v]) { my_sc[p] = my_sc[p - 1]; my_id[p] = my_id[p - 1]; --p; }
+              while (p > 0 && my_sc[p - 1] < sg[v]) {
+                const float ps = my_sc[p - 1];
+                const int pi = my_id[p - 1];
+                my_sc[p] = ps;
+                my_id[p] = pi;
+                --p;
+              }
               my_sc[p] = sg[v];
               my_id[p] = static_cast<int>(item);
             }
           }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
   }

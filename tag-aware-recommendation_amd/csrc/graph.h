@@ -14,8 +14,8 @@ struct tagrec_graph {
   int32_t* long_rows;
   int32_t* long_base;
   int2* chunk_desc;
-  mutable float* slab;        // n_chunks x D partial sums, grown on demand
-  mutable size_t slab_floats;
+  float* slab;                // n_chunks x kSlabWidth partial sums, allocated with the handle (scratch of the launch in
+  size_t slab_floats;         // flight: one stream per handle)
   bool owns_long;             // false: long_rows / long_base / chunk_desc belong to the graph this one was created like
 };
 
@@ -24,12 +24,14 @@ namespace tagrec {
 constexpr int kWavesPerBlock = 4;
 constexpr int kLongRow = 1024;   // rows with more stored entries are cut into chunks
 constexpr int kChunk = 512;      // entries per chunk (one wavefront each)
+constexpr int kSlabWidth = 256;  // floats per chunk in the partial-sum slab = widest vector kernel
 
 struct GraphView {
   int64_t n_rows;
   const int64_t* rowptr;
   const int32_t* col;
   const float* val;
+  int64_t n_cols;           // rows of the gathered operand: what the row flags of that operand are counted against
 };
 
 // The FIRST `chunk_blocks` blocks of a row-walking launch take the long-row chunks.
@@ -41,7 +43,7 @@ struct LongView {
   unsigned chunk_blocks;
 };
 
-// Grow g->slab to n_chunks x width floats.
+// Check that g->slab (allocated at creation) holds n_chunks x width floats.
 int ensure_slab(const tagrec_graph* g, int width);
 
 // *count = number of non-zero bytes of flags[0..n) (rowops.hip)

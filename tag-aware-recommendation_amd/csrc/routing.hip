@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void route_spmm_kernel(Grap
   __shared__ WaveStage<K> stage[kWavesPerBlock];
   const int lane = threadIdx.x & (kWave - 1);
   WaveStage<K>& st = stage[threadIdx.x >> 6];
-  const uint8_t* flags = (e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_rows)) ? e.in_flags : nullptr;
+  const uint8_t* flags = (e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_cols)) ? e.in_flags : nullptr;
   if (blockIdx.x < lv.chunk_blocks) {
     const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (c >= lv.n_chunks) return;

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
     const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
-    const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_rows);
+    const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_cols);
     const float4 acc = sparse ? gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags) : gather_rows<LPR>(g, X, start, end, lane);
     if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[c * LPR + lane] = acc;
     return;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
   if (MASKED && !e.row_mask[r]) return;
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
   if (end - start > kLongRow) return;  // chunked above, folded by spmm_finish_kernel
-  const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_rows);
+  const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_cols);
   const float4 acc = sparse ? gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags) : gather_rows<LPR>(g, X, start, end, lane);
   row_epilogue<LPR, EPI>(acc, r, lane, e);
 }
@@ -357,13 +357,45 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_generic_kern
   }
 }
 
+
+// ---- product on a short LIST of rows, compact output: Y[k, :] = sum_j val_j X[col_j, :] over row rows[k] ----------
+// One block per listed row; its four waves take contiguous quarters of the row (multiples of 64 entries) and the
+// partial sums are folded in wave order through LDS, so the result is reproducible.  This is the top layer of the
+// row-sharded step (dist.py): the loss reads that layer at the <= 3 B batch rows only, and each rank adds the part of
+// those rows' neighbourhoods it owns.
+template <int LPR>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_listed_kernel(GraphView g, const int64_t* __restrict__ rows,
+                                                                              const float* __restrict__ X, float* __restrict__ Y) {
+  __shared__ float4 part[kWavesPerBlock][LPR];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int64_t k = blockIdx.x;
+  const int64_t r = rows[k];
+  const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
+  const int64_t per = ((end - start + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave)) * kWave;
+  const int64_t s0 = (start + wave * per < end) ? start + wave * per : end;
+  const int64_t s1 = (s0 + per < end) ? s0 + per : end;
+  const float4 acc = gather_rows<LPR>(g, X, s0, s1, lane);
+  if (lane < LPR) part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && lane < LPR) {
+    float4 a = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+      const float4 b = part[w][lane];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(Y)[k * LPR + lane] = a;
+  }
+}
+
 // flags[c] = 1 for every column index stored in the listed rows, and for the rows themselves (block per listed row)
+template <bool SELF>
 __global__ __launch_bounds__(256) void mark_rows_kernel(GraphView g, const int64_t* __restrict__ rows, int64_t n_listed,
                                                         uint8_t* __restrict__ flags) {
   const int64_t i = blockIdx.x;
   if (i >= n_listed) return;
   const int64_t r = rows[i];
-  if (threadIdx.x == 0) flags[r] = 1;
+  if (SELF && threadIdx.x == 0) flags[r] = 1;
   for (int64_t j = g.rowptr[r] + threadIdx.x; j < g.rowptr[r + 1]; j += blockDim.x) flags[g.col[j]] = 1;
 }
 
@@ -415,6 +447,7 @@ extern "C" int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n
     if (err != hipSuccess) { delete g; return fail(TAGREC_E_HIP, std::string("graph_create: hipMalloc: ") + hipGetErrorString(err)); }
     auto bail = [&](const char* what, hipError_t e2) {
       (void)hipFree(counters); (void)hipFree(g->long_rows); (void)hipFree(g->long_base); (void)hipFree(g->chunk_desc);
+      (void)hipFree(g->slab);
       delete g;
       return fail(TAGREC_E_HIP, std::string("graph_create: ") + what + ": " + hipGetErrorString(e2));
     };
@@ -435,6 +468,9 @@ extern "C" int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n
       fill_long_kernel<<<blocks, threads, 0, s>>>(rowptr, n_rows, counters, g->long_rows, g->long_base, g->chunk_desc);
       if ((err = hipGetLastError()) != hipSuccess) return bail("fill_long launch", err);
       if ((err = hipStreamSynchronize(s)) != hipSuccess) return bail("sync", err);
+      // partial-sum slab of the long-row chunks, sized once for the widest vector kernel: no later call allocates
+      if ((err = hipMalloc(&g->slab, sizeof(float) * kSlabWidth * g->n_chunks)) != hipSuccess) return bail("hipMalloc slab", err);
+      g->slab_floats = static_cast<size_t>(kSlabWidth) * g->n_chunks;
     }
     (void)hipFree(counters);
   }
@@ -455,6 +491,11 @@ extern "C" int tagrec_graph_create_like(tagrec_graph** out, const tagrec_graph* 
   g->slab = nullptr;
   g->slab_floats = 0;
   g->owns_long = false;
+  if (g->n_chunks > 0) {   // its own slab: the two matrices may be multiplied back to back on one stream
+    hipError_t err = hipMalloc(&g->slab, sizeof(float) * kSlabWidth * g->n_chunks);
+    if (err != hipSuccess) { delete g; return fail(TAGREC_E_HIP, std::string("graph_create_like: hipMalloc slab: ") + hipGetErrorString(err)); }
+    g->slab_floats = static_cast<size_t>(kSlabWidth) * g->n_chunks;
+  }
   *out = g;
   return TAGREC_OK;
 }
@@ -483,14 +524,12 @@ extern "C" int tagrec_graph_info(const tagrec_graph* g, int64_t* n_rows, int64_t
 }
 
 int tagrec::ensure_slab(const tagrec_graph* g, int D) {
+  // The slab is allocated when the handle is created (kSlabWidth floats per chunk); nothing is allocated or freed inside
+  // an asynchronous entry point, so calls are safe under stream capture.
   const size_t need = static_cast<size_t>(g->n_chunks) * D;
   if (need <= g->slab_floats) return TAGREC_OK;
-  if (g->slab) TAGREC_HIP(hipFree(g->slab));
-  g->slab = nullptr;
-  g->slab_floats = 0;
-  TAGREC_HIP(hipMalloc(&g->slab, need * sizeof(float)));
-  g->slab_floats = need;
-  return TAGREC_OK;
+  return fail(TAGREC_E_UNSUPPORTED, "long-row slab: row width " + std::to_string(D) + " exceeds the " +
+                                        std::to_string(kSlabWidth) + " floats per chunk reserved at graph creation");
 }
 
 namespace {
@@ -551,6 +590,9 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
       default: break;
     }
   }
+  if (e.row_mask || e.in_flags || e.out_flags)
+    return fail(TAGREC_E_INVALID, std::string(who) + ": row masks / row flags need the vector kernels (D in {8,...,256}, "
+                                                     "every operand 16-byte aligned); the scalar kernel would ignore them");
   if (D > kMaxGenericBlocks * kWave)
     return fail(TAGREC_E_UNSUPPORTED, std::string(who) + ": row width " + std::to_string(D) + " > 512 is not covered");
   const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
@@ -675,7 +717,41 @@ extern "C" int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* r
   TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "graph_mark_rows: bad row count");
   if (n_listed == 0) return TAGREC_OK;
   const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
-  mark_rows_kernel<<<static_cast<unsigned>(n_listed), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
+  mark_rows_kernel<true><<<static_cast<unsigned>(n_listed), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_graph_mark_cols_u8(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, uint8_t* flags,
+                                         void* stream) {
+  TAGREC_REQUIRE(g != nullptr && flags != nullptr && (n_listed == 0 || rows != nullptr), "graph_mark_cols: null pointer");
+  TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "graph_mark_cols: bad row count");
+  if (n_listed == 0) return TAGREC_OK;
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  mark_rows_kernel<false><<<static_cast<unsigned>(n_listed), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_spmm_listed_f32(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, const float* X, float* Y,
+                                      int D, void* stream) {
+  TAGREC_REQUIRE(g != nullptr && X != nullptr && Y != nullptr && (n_listed == 0 || rows != nullptr), "spmm_listed: null pointer");
+  TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "spmm_listed: bad row count");
+  TAGREC_REQUIRE(aligned16(X) && aligned16(Y), "spmm_listed: rows must be 16-byte aligned");
+  if (n_listed == 0) return TAGREC_OK;
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned blocks = static_cast<unsigned>(n_listed);
+  const int threads = kWavesPerBlock * kWave;
+  switch (D) {
+    case 8: spmm_listed_kernel<2><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
+    case 16: spmm_listed_kernel<4><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
+    case 32: spmm_listed_kernel<8><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
+    case 64: spmm_listed_kernel<16><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
+    case 128: spmm_listed_kernel<32><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
+    case 256: spmm_listed_kernel<64><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
+    default: return fail(TAGREC_E_UNSUPPORTED, "spmm_listed: D must be 8 .. 256, a power of two");
+  }
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

@@ -42,19 +42,64 @@ class HipOps:
     def make_graph(self, rowptr, col, val, shape):
         return Graph(rowptr.contiguous(), col.contiguous(), val.contiguous(), shape)
 
-    def spmm_norm_acc(self, g, x, y, inv, acc, s):
-        g.spmm_norm_acc(x, y, inv, acc, s)
+    # -- row-sharded tables ------------------------------------------------------------------------
+    row_sparse_backward = True       # gradient tables travel with one flag byte per row; zero rows are not gathered
 
-    def spmm_normbwd(self, g, g_in, x_raw, inv, dz, s, out):
-        g.spmm_normbwd(g_in, x_raw, inv, dz, s, out)
+    def row_block(self, rowptr, col, val, lo, hi, n_cols):
+        """Handle on rows [lo, hi) of a CSR matrix: the row pointer is a VIEW (its entries stay absolute offsets into the
+        shared col / val arrays), so the row blocks of a shard cost no copy."""
+        return Graph(rowptr[lo:hi + 1], col, val, (hi - lo, n_cols))
 
-    def spmm_axpy(self, g, g_in, b, s, out):
-        g.spmm_axpy(g_in, b, s, out)
+    def mark_cols(self, g, rows, flags):
+        rows = rows.contiguous()
+        _lib.check(_lib.load().tagrec_graph_mark_cols_u8(g.handle, _lib.ptr(rows), rows.numel(), _lib.ptr(flags),
+                                                         _lib.stream_ptr()), "graph_mark_cols")
+
+    def spmm_listed(self, g, rows, x, out):
+        rows = rows.contiguous()
+        g._call("spmm_listed", _lib.load().tagrec_spmm_listed_f32, g.handle, _lib.ptr(rows), rows.numel(), _lib.ptr(x),
+                _lib.ptr(out), x.shape[1], _lib.stream_ptr())
+
+    def layer_fwd(self, g, x_full, y, inv, acc, s, row_mask=None):
+        if row_mask is None:
+            g.spmm_norm_acc(x_full, y, inv, acc, s)
+        else:
+            g.spmm_norm_acc_rows(x_full, y, inv, acc, s, row_mask)
+
+    def layer_bwd(self, g, g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, row_mask=None):
+        if in_flags is None and out_flags is None and row_mask is None:
+            g.spmm_normbwd(g_in, x_raw, inv, dz, s, out)
+            return
+        cnt = torch.empty(1, dtype=torch.int32, device=out.device) if out_flags is not None else None
+        g.spmm_normbwd_sparse(g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, cnt, row_mask=row_mask)
+
+    def last_hop(self, g, g_in, in_flags, in_count, b, s, out):
+        if in_flags is None:
+            g.spmm_axpy(g_in, b, s, out)
+        else:
+            g.spmm_axpy_sparse(g_in, in_flags, in_count, b, s, out)
+
+    def rownorm_fwd(self, x):
+        n, D = x.shape
+        z = torch.empty_like(x)
+        inv = torch.empty(n, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().tagrec_rownorm_fwd_f32(_lib.ptr(x), _lib.ptr(z), D, _lib.ptr(inv), n, D, _lib.stream_ptr()),
+                   "rownorm_fwd")
+        return z, inv
 
     def rownorm_bwd(self, x_raw, inv, dz, s, out):
         n, D = x_raw.shape
         _lib.check(_lib.load().tagrec_rownorm_bwd_f32(_lib.ptr(x_raw), _lib.ptr(inv), _lib.ptr(dz), D, s,
                                                       _lib.ptr(out), 0, n, D, _lib.stream_ptr()), "rownorm_bwd")
+
+    def rownorm_bwd_flags(self, x_raw, inv, dz, s, out):
+        n, D = x_raw.shape
+        flags = torch.empty(n, dtype=torch.uint8, device=out.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=out.device)
+        _lib.check(_lib.load().tagrec_rownorm_bwd_flags_f32(_lib.ptr(x_raw), _lib.ptr(inv), _lib.ptr(dz), D, s, _lib.ptr(out), 0,
+                                                            n, D, _lib.ptr(flags), _lib.ptr(cnt), _lib.stream_ptr()),
+                   "rownorm_bwd_flags")
+        return flags
 
     def bpr_fwd(self, U, I, Ur, Ir, trip, kind):
         B, D = trip.shape[0], U.shape[1]
@@ -75,6 +120,9 @@ class HipOps:
 
 
     # -- column-sharded tables -------------------------------------------------------------------
+    def spmm_axpy(self, g, g_in, b, s, out):
+        g.spmm_axpy(g_in, b, s, out)
+
     def spmm_ss(self, g, x, y, ss):
         g._call("spmm_ss", _lib.load().tagrec_spmm_ss_f32, g.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(ss), x.shape[1],
                 _lib.stream_ptr())
@@ -141,10 +189,10 @@ class HipOps:
         return dots
 
 
-def shard_rows(n, world):
-    """Rows per rank (ceil) and the padded total."""
-    per = (n + world - 1) // world
-    return per, per * world
+def shard_rows(n, world, n_chunks=1):
+    """Rows per rank (a multiple of n_chunks, rounded up) and the padded total."""
+    rc = (n + world * n_chunks - 1) // (world * n_chunks)
+    return rc * n_chunks, rc * n_chunks * world
 
 
 def local_csr(rowptr, col, val, lo, hi, per):
@@ -158,75 +206,259 @@ def local_csr(rowptr, col, val, lo, hi, per):
     return rp.contiguous(), col[a:b].contiguous(), val[a:b].contiguous()
 
 
+class RowPartition:
+    """The 1-D fold partition of adj.py:114-140 over `world` ranks, plus the layout of a gathered table.
+
+    Rank h owns the original rows [h R, (h+1) R) (R = `per`; the tail is zero padding).  A shard is exchanged in
+    `n_chunks` row blocks of Rc = R / n_chunks rows so that the all-gather of block c can run while block c+1 is still
+    being computed; `all_gather_into_tensor` wants a contiguous destination, so a gathered table is laid out
+    [chunk][rank][row in chunk]: original row j = h R + c Rc + i sits at position p = c (G Rc) + h Rc + i.  The column
+    indices of the local matrices are rewritten to p once, at construction; with one chunk p == j."""
+
+    def __init__(self, n_nodes, world, n_chunks=1):
+        self.n, self.world, self.n_chunks = int(n_nodes), int(world), int(n_chunks)
+        self.per, self.n_pad = shard_rows(self.n, self.world, self.n_chunks)
+        self.rc = self.per // self.n_chunks
+
+    def owner(self, ids):
+        return torch.div(ids, self.per, rounding_mode="floor")
+
+    def local(self, ids):
+        return ids - self.owner(ids) * self.per
+
+    def gathered(self, ids):
+        h = self.owner(ids)
+        loc = ids - h * self.per
+        c = torch.div(loc, self.rc, rounding_mode="floor")
+        return c * (self.world * self.rc) + h * self.rc + (loc - c * self.rc)
+
+    def chunk_rows(self, c):
+        """Local rows of block c."""
+        return slice(c * self.rc, (c + 1) * self.rc)
+
+    def chunk_gathered(self, c):
+        """Positions of block c (all ranks) in a gathered table."""
+        return slice(c * self.world * self.rc, (c + 1) * self.world * self.rc)
+
+
+def transpose_csr(rowptr, col, val, n_cols):
+    """(rowptr, col, val) of the transposed matrix; torch ops only (runs on the GPU and in the CPU tests)."""
+    n_rows = rowptr.numel() - 1
+    deg = rowptr[1:] - rowptr[:-1]
+    rows = torch.repeat_interleave(torch.arange(n_rows, device=rowptr.device), deg)
+    key = col.to(torch.int64) * n_rows + rows
+    key, order = torch.sort(key)
+    trow = torch.div(key, n_rows, rounding_mode="floor")
+    rp = torch.zeros(n_cols + 1, dtype=torch.int64, device=rowptr.device)
+    torch.cumsum(torch.bincount(trow, minlength=n_cols), 0, out=rp[1:])
+    return rp, (key - trow * n_rows).to(torch.int32), val[order].contiguous()
+
+
+class _Gather:
+    """One table being all-gathered block by block.  `put(c, x_block)` starts the all-gather of block c (asynchronous:
+    with RCCL it runs on the process group's stream behind an event of the producing stream, so the next block's
+    kernels overlap it); `table()` waits for every block and returns the [n_pad, D] gathered table."""
+
+    def __init__(self, model, width, dtype=torch.float32, key="table"):
+        m = model
+        self.m, self.key = m, key
+        shape = (m.part.n_pad,) if width is None else (m.part.n_pad, width)
+        self.full = m._scratch((key, width, dtype), shape, dtype)
+        self.works = []
+
+    def put(self, c, block):
+        m = self.m
+        dst = self.full[m.part.chunk_gathered(c)]
+        if m.world == 1:
+            dst.copy_(block)
+            return
+        m.comm_bytes += block.numel() * block.element_size() * (m.world - 1)
+        self.works.append(dist.all_gather_into_tensor(dst, block.contiguous(), group=m.group, async_op=True))
+
+    def put_all(self, x):
+        for c in range(self.m.part.n_chunks):
+            self.put(c, x[self.m.part.chunk_rows(c)])
+        return self
+
+    def table(self):
+        ev = self.m._wait_begin()
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.m._wait_end(ev, "all_gather_wait")
+        return self.full
+
+
 class _ShardedLoss(torch.autograd.Function):
+    """table shard -> [mul_loss, l2reg_loss(ego rows)] for a replicated batch; see ShardedLightGCN."""
+
     @staticmethod
     def forward(ctx, table, model, trip):
-        m = model
+        m, ops, part = model, model.ops, model.part
         x0 = table.detach()
-        L, s = m.num_layer, 1.0 / (m.num_layer + 1)
+        L, s, D = m.num_layer, 1.0 / (m.num_layer + 1), x0.shape[1]
+        B = trip.shape[0]
+        T = 3 * B
+        dev = x0.device
+        rows = torch.cat([trip[:, 0], m.n_user + trip[:, 1], m.n_user + trip[:, 2]])      # original node ids, [T]
+        rows_p = part.gathered(rows)
+        slot = torch.nonzero(part.owner(rows) == m.rank).flatten()                       # batch slots this rank owns
+        loc = rows[slot] - m.lo
+        vec = D in (8, 16, 32, 64, 128, 256)
+        restricted = bool(m.restrict_forward and getattr(ops, "restrict_forward", False) and L >= 1 and vec
+                          and T * m.restrict_min_ratio <= part.n)
         out = x0 * s
         raws, invs = [], []
+        mid_mask = None
+        if restricted and L >= 2:
+            # rows of layer L-1 the batch depends on = the batch rows and their neighbours; the column slice lists, for
+            # every node, the neighbours THIS rank owns, so the local part of the mask needs no exchange
+            mid_mask = torch.zeros(part.per, dtype=torch.uint8, device=dev)
+            ops.mark_cols(m.graph_cols, rows_p, mid_mask)
+            mid_mask.index_fill_(0, loc, 1)
+        n_pull = L - 1 if restricted else L               # layers computed as pull products on (a subset of) the local rows
         x = x0
-        for _ in range(L):
-            full = m.all_gather(x)
-            y = torch.empty_like(x0)
-            inv = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
-            m.ops.spmm_norm_acc(m.graph, full, y, inv, out, s)
+        gat = _Gather(m, D, key="fwd").put_all(x0) if n_pull > 0 else None
+        for k in range(n_pull):
+            masked = restricted and k == L - 2
+            xf = gat.table()
+            feeds_pull = k + 1 < n_pull                    # its output is gathered for the next pull layer
+            gat = _Gather(m, D, key=("fwd", k & 1)) if feeds_pull else None
+            if masked:
+                y = torch.zeros_like(x0)
+                inv = torch.zeros(part.per, dtype=torch.float32, device=dev)
+            else:
+                y = torch.empty_like(x0)
+                inv = torch.empty(part.per, dtype=torch.float32, device=dev)
+            for c in range(part.n_chunks):
+                r = part.chunk_rows(c)
+                ops.layer_fwd(m.graph_chunks[c], xf, y[r], inv[r], out[r], s, mid_mask[r] if masked else None)
+                if feeds_pull:
+                    gat.put(c, y[r])
             raws.append(y)
             invs.append(inv)
             x = y
-        # batch rows: [u | p | n] from the propagated table, then the same from the ego table
-        B = trip.shape[0]
-        rows = torch.cat([trip[:, 0], m.n_user + trip[:, 1], m.n_user + trip[:, 2]])
-        mine = (rows >= m.lo) & (rows < m.hi)
-        loc = rows[mine] - m.lo
-        compact = torch.zeros(6 * B, x0.shape[1], dtype=torch.float32, device=x0.device)
-        idx = torch.nonzero(mine).flatten()
-        compact[idx] = out[loc]
-        compact[idx + 3 * B] = x0[loc]
-        m.all_reduce(compact)
-        ar = torch.arange(B, device=x0.device)
+        # batch rows: every rank contributes what it owns to a [*, T, D] buffer, one all-reduce completes it
+        buf = torch.zeros(3 if restricted else 2, T, D, dtype=torch.float32, device=dev)
+        buf[0][slot] = out[loc]
+        buf[1][slot] = x0[loc]
+        if restricted:
+            # top layer in push form: this rank's share of (A x)[batch rows] from the rows of x it owns
+            ops.spmm_listed(m.graph_cols, rows_p, x, buf[2])
+        m.all_reduce(buf, "batch_rows")
+        out_b, ego_b = buf[0], buf[1]
+        y_top = inv_top = None
+        if restricted:
+            y_top = buf[2]
+            z_top, inv_top = ops.rownorm_fwd(y_top)
+            out_b = out_b + s * z_top
+        ar = torch.arange(B, device=dev)
         ctrip = torch.stack([ar, ar, ar + B], dim=1).contiguous()
-        res, coef = m.ops.bpr_fwd(compact[:B], compact[B:3 * B], compact[3 * B:4 * B], compact[4 * B:], ctrip,
-                                  H.loss_kind_id(m.loss_func))
-        ctx.m, ctx.raws, ctx.invs = m, raws, invs
-        ctx.compact, ctx.ctrip, ctx.coef, ctx.idx, ctx.loc = compact, ctrip, coef, idx, loc
+        res, coef = ops.bpr_fwd(out_b[:B], out_b[B:], ego_b[:B], ego_b[B:], ctrip, H.loss_kind_id(m.loss_func))
+        ctx.m, ctx.raws, ctx.invs, ctx.restricted, ctx.mid_mask = m, raws, invs, restricted, mid_mask
+        ctx.out_b, ctx.ego_b, ctx.ctrip, ctx.coef = out_b.contiguous(), ego_b, ctrip, coef
+        ctx.rows_p, ctx.slot, ctx.loc, ctx.y_top, ctx.inv_top = rows_p, slot, loc, y_top, inv_top
+        ctx.shape = x0.shape
         return res
 
     @staticmethod
     def backward(ctx, g):
         m, raws, invs = ctx.m, ctx.raws, ctx.invs
-        compact, B = ctx.compact, ctx.ctrip.shape[0]
+        ops, part = m.ops, m.part
+        out_b, ego_b, ctrip = ctx.out_b, ctx.ego_b, ctx.ctrip
+        B = ctrip.shape[0]
+        T, D = 3 * B, ctx.shape[1]
         L, s = m.num_layer, 1.0 / (m.num_layer + 1)
-        dcomp = torch.zeros_like(compact)
-        m.ops.bpr_bwd(compact[:B], compact[B:3 * B], compact[3 * B:4 * B], compact[4 * B:], ctx.ctrip, ctx.coef,
-                      g.contiguous(), dcomp[:B], dcomp[B:3 * B], dcomp[3 * B:4 * B], dcomp[4 * B:])
-        d_out = torch.zeros_like(raws[0]) if L else torch.zeros(m.per, compact.shape[1], device=compact.device)
-        d_out.index_add_(0, ctx.loc, dcomp[ctx.idx])
+        dev = out_b.device
+        restricted = ctx.restricted
+        vec = D in (8, 16, 32, 64, 128, 256)
+        sparse = vec and getattr(ops, "row_sparse_backward", False)
+        d_b = torch.zeros(2, T, D, dtype=torch.float32, device=dev)        # d loss / d out_b, d loss / d ego_b (replicated)
+        ops.bpr_bwd(out_b[:B], out_b[B:], ego_b[:B], ego_b[B:], ctrip, ctx.coef, g.contiguous(),
+                    d_b[0][:B], d_b[0][B:], d_b[1][:B], d_b[1][B:])
+        d_out = torch.zeros(ctx.shape, dtype=torch.float32, device=dev)    # gradient w.r.t. `out`, local rows
+        d_out.index_add_(0, ctx.loc, d_b[0][ctx.slot])
+        n_pull = len(raws)
+        # ---- head of the chain: G^L, either on the batch rows (restricted) or on the local rows
         if L == 0:
             g0 = d_out
         else:
-            gl = torch.empty_like(d_out)
-            m.ops.rownorm_bwd(raws[L - 1], invs[L - 1], d_out, s, gl)
-            for k in range(L - 2, -1, -1):
-                full = m.all_gather(gl)
-                gn = torch.empty_like(d_out)
-                m.ops.spmm_normbwd(m.graph, full, raws[k], invs[k], d_out, s, gn)
-                gl = gn
-            full = m.all_gather(gl)
+            if restricted:
+                g_top = torch.empty(T, D, dtype=torch.float32, device=dev)
+                ops.rownorm_bwd(ctx.y_top, ctx.inv_top, d_b[0], s, g_top)
+                # the operand of the next product: zero except at the batch rows (slots naming one node are summed)
+                gfull = m._scratch(("bwd", D, 0), (part.n_pad, D), torch.float32)
+                gfull.index_fill_(0, ctx.rows_p, 0.0)
+                gfull.index_add_(0, ctx.rows_p, g_top)
+                flags = torch.zeros(part.n_pad, dtype=torch.uint8, device=dev)
+                flags.index_fill_(0, ctx.rows_p, 1)
+                count = torch.full((1,), T, dtype=torch.int32, device=dev)
+                operand = (gfull, flags if sparse else None, count if sparse else None)
+                if not sparse:
+                    raise _lib.TagrecError("restricted sharded step needs the row-flag kernels")
+            else:
+                gl = torch.empty_like(d_out)
+                fl = ops.rownorm_bwd_flags(raws[L - 1], invs[L - 1], d_out, s, gl) if sparse else None
+                if not sparse:
+                    ops.rownorm_bwd(raws[L - 1], invs[L - 1], d_out, s, gl)
+                operand = m._gather_grad(gl, fl, (L - 1) & 1)
+            # ---- hops: G^k = A G^(k+1) + nb(X^k) on the local rows, gathered for the next hop
+            first = n_pull - 1 if restricted else n_pull - 2          # index into raws of the layer the first hop lands on
+            for k in range(first, -1, -1):
+                masked = restricted and k == n_pull - 1
+                gn = torch.zeros_like(d_out) if masked else torch.empty_like(d_out)
+                fo = None
+                if sparse:
+                    fo = (torch.zeros if masked else torch.empty)(part.per, dtype=torch.uint8, device=dev)
+                gat = m._grad_gather(D, k & 1, sparse)
+                for c in range(part.n_chunks):
+                    r = part.chunk_rows(c)
+                    ops.layer_bwd(m.graph_chunks[c], operand[0], operand[1], operand[2], raws[k][r], invs[k][r], d_out[r], s,
+                                  gn[r], fo[r] if sparse else None, ctx.mid_mask[r] if masked else None)
+                    gat.put(c, gn[r], fo[r] if sparse else None)
+                operand = gat.result()
             g0 = torch.empty_like(d_out)
-            m.ops.spmm_axpy(m.graph, full, d_out, s, g0)
-        g0.index_add_(0, ctx.loc, dcomp[ctx.idx + 3 * B])        # L2 term on the ego rows
-        ctx.raws = ctx.invs = ctx.compact = None
+            for c in range(part.n_chunks):
+                r = part.chunk_rows(c)
+                ops.last_hop(m.graph_chunks[c], operand[0], operand[1], operand[2], d_out[r], s, g0[r])
+        g0.index_add_(0, ctx.loc, d_b[1][ctx.slot])                      # L2 term on the ego rows this rank owns
+        ctx.raws = ctx.invs = ctx.y_top = None
         return g0, None, None
 
 
-class ShardedLightGCN(torch.nn.Module):
-    """LightGCN with the node table row-sharded over the ranks of the default process group.
-    Same `loss(batch)` / `forward()` / `parameters()` surface as `LightGCN`; every rank must call
-    them with the same batch."""
+class _GradGather:
+    """`_Gather` of a gradient block together with its row flags; result() = (table, flags, count) for the next product."""
 
-    def __init__(self, data, config, rowptr, col, val, n_nodes, ops=None, group=None):
+    def __init__(self, model, width, parity, sparse):
+        self.m = model
+        self.g = _Gather(model, width, key=("bwd", parity))
+        self.f = _Gather(model, None, torch.uint8, key=("bwdf", parity)) if sparse else None
+
+    def put(self, c, block, flags):
+        self.g.put(c, block)
+        if self.f is not None:
+            self.f.put(c, flags)
+
+    def result(self):
+        full = self.g.table()
+        if self.f is None:
+            return full, None, None
+        fl = self.f.table()
+        return full, fl, fl.sum(dtype=torch.int32).reshape(1)
+
+
+class ShardedLightGCN(torch.nn.Module):
+    """LightGCN with the node table ROW-sharded over the ranks of the process group (module docstring).
+    Same `loss(batch)` / `forward()` / `parameters()` surface as `LightGCN`; every rank must call them with the same
+    batch.  Needs a symmetric adjacency (bi_norm / plain): the backward product (A^T G)[rows_g] is then the same pull
+    over A[rows_g, :]; other normalisations raise.
+
+    n_chunks: row blocks per shard for the pipelined all-gathers (default 4 with more than one rank).
+    timing: set to {} to collect, per step, the milliseconds the compute stream waited for collectives."""
+
+    restrict_min_ratio = 16          # the restricted step is used when 3 B * this <= number of nodes
+
+    def __init__(self, data, config, rowptr, col, val, n_nodes, ops=None, group=None, n_chunks=None, symmetric=None):
         super().__init__()
         self.ops = ops if ops is not None else HipOps()
         self.group = group
@@ -237,12 +469,29 @@ class ShardedLightGCN(torch.nn.Module):
         self.dim_latent = config["dim_latent"]
         self.reg = config["reg"]
         self.loss_func = config["mul_loss_func"]
+        self.restrict_forward = bool(config.get("restrict_forward", True))
+        if symmetric is None:
+            symmetric = config.get("norm_type", "bi_norm") in ("bi_norm", "plain")
+        if not symmetric:
+            raise _lib.TagrecError(
+                f"ShardedLightGCN: norm_type {config.get('norm_type')!r} is not symmetric; the row-sharded backward multiplies by "
+                "A[rows_g, :] in place of (A^T G)[rows_g] and would be wrong (use bi_norm, or the single-GPU model)")
         self.n_user, self.n_item = data.num["user"], data.num["item"]
         self.n_nodes = int(n_nodes)
-        self.per, self.n_pad = shard_rows(self.n_nodes, self.world)
+        if n_chunks is None:
+            n_chunks = 4 if self.world > 1 else 1
+        self.part = RowPartition(self.n_nodes, self.world, n_chunks)
+        self.per, self.n_pad = self.part.per, self.part.n_pad
         self.lo, self.hi = self.rank * self.per, (self.rank + 1) * self.per
         rp, c, v = local_csr(rowptr, col, val, self.lo, self.hi, self.per)
-        self.graph = self.ops.make_graph(rp, c, v, (self.per, self.n_pad))
+        c = self.part.gathered(c.to(torch.int64)).to(torch.int32).contiguous()     # entry order within a row is kept
+        # row slice A[rows_g, :] (pull products), as a whole and per row block; column slice A[:, rows_g] = its transpose
+        self.graph = self.ops.row_block(rp, c, v, 0, self.per, self.n_pad)
+        self.graph_chunks = ([self.graph] if n_chunks == 1 else
+                             [self.ops.row_block(rp, c, v, k * self.part.rc, (k + 1) * self.part.rc, self.n_pad)
+                              for k in range(n_chunks)])
+        trp, tc, tv = transpose_csr(rp, c, v, self.n_pad)
+        self.graph_cols = self.ops.row_block(trp, tc, tv, 0, self.n_pad, self.per)
         num_list = [self.n_user, self.n_item] + ([data.num["tag"]] if config["use_tag"] else [])
         assert sum(num_list) == self.n_nodes
         full = xavier_tables(num_list, self.dim_latent, "cpu")         # same seed on every rank -> same table
@@ -252,19 +501,62 @@ class ShardedLightGCN(torch.nn.Module):
             local[:real_hi - self.lo] = full[self.lo:real_hi]
         del full
         self.table = torch.nn.Parameter(local.to(self.device))
+        self._buffers_cache = {}
+        self.timing = None
+        self.comm_bytes = 0
+
+    # -- scratch: gathered tables are reused from step to step (no 512 MB allocations inside the step) -------------
+    def _scratch(self, key, shape, dtype):
+        t = self._buffers_cache.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buffers_cache[key] = t
+        return t
 
     # -- collectives (torch.distributed: RCCL on GPUs, gloo in the CPU tests) ---------------------
+    def _wait_begin(self):
+        if self.timing is None or self.device.type != "cuda":
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _wait_end(self, e0, name):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.timing.setdefault(name, []).append((e0, e1))
+
+    def timing_ms(self):
+        torch.cuda.synchronize(self.device)
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.timing or {}).items()}
+
     def all_gather(self, x):
+        """[per, D] shard -> the gathered [n_pad, D] table in ORIGINAL row order (setup / evaluation helper)."""
         if self.world == 1:
             return x.contiguous()
-        full = torch.empty(self.n_pad, x.shape[1], dtype=x.dtype, device=x.device)
+        full = torch.empty((self.n_pad,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(full, x.contiguous(), group=self.group)
         return full
 
-    def all_reduce(self, x):
+    def all_reduce(self, x, name="all_reduce"):
         if self.world > 1:
+            e = self._wait_begin()
+            self.comm_bytes += x.numel() * x.element_size()
             dist.all_reduce(x, group=self.group)
+            self._wait_end(e, name)
         return x
+
+    def _grad_gather(self, width, parity, sparse):
+        return _GradGather(self, width, parity, sparse)
+
+    def _gather_grad(self, g_local, flags_local, parity):
+        gat = self._grad_gather(g_local.shape[1], parity, flags_local is not None)
+        for c in range(self.part.n_chunks):
+            r = self.part.chunk_rows(c)
+            gat.put(c, g_local[r], flags_local[r] if flags_local is not None else None)
+        return gat.result()
 
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
@@ -273,15 +565,18 @@ class ShardedLightGCN(torch.nn.Module):
 
     @torch.no_grad()
     def forward(self):
-        """Full propagated tables, gathered on every rank (evaluation path)."""
+        """Full propagated tables, gathered on every rank (evaluation path): every layer on all rows."""
         L, s = self.num_layer, 1.0 / (self.num_layer + 1)
         x0 = self.table.detach()
         out = x0 * s
         x = x0
         for _ in range(L):
+            xf = _Gather(self, x0.shape[1], key="fwd").put_all(x).table()
             y = torch.empty_like(x0)
             inv = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
-            self.ops.spmm_norm_acc(self.graph, self.all_gather(x), y, inv, out, s)
+            for c in range(self.part.n_chunks):
+                r = self.part.chunk_rows(c)
+                self.ops.layer_fwd(self.graph_chunks[c], xf, y[r], inv[r], out[r], s, None)
             x = y
         full = self.all_gather(out)[:self.n_nodes]
         return full[:self.n_user], full[self.n_user:self.n_user + self.n_item]

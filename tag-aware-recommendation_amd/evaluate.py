@@ -104,7 +104,9 @@ class Basic_test:
         auc_sum = torch.zeros((), dtype=torch.float64, device=self.device)
 
         def score(users, top):
-            label = _member(key, users[:, None] * self.n_item + top).to(torch.float64)     # get_label
+            label = _member(key, users[:, None] * self.n_item + top.clamp_min(0))            # get_label
+            # the fused kernel pads a list with id -1 when a user has fewer than k un-masked items: never a hit
+            label = (label & (top >= 0)).to(torch.float64)
             n_true = cnt[users].to(torch.float64)
             for j, k in enumerate(topks):
                 right = label[:, :k].sum(1)

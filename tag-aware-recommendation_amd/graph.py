@@ -118,33 +118,77 @@ def coalesce_device(rows, cols, vals, n_r, n_c):
     return rowptr, (ukey - urow * n_c).to(torch.int32), uval.to(torch.float32)
 
 
-def bipartite_norm_device(u, i, n_user, n_item, norm_type="bi_norm"):
-    """User-item adjacency straight on the GPU: u, i int64 tensors of DISTINCT pairs.
-    Returns (rowptr, col, val, n).  Same formulas as `normalise_host`."""
-    n = n_user + n_item
-    rows = torch.cat([u, i + n_user])
-    cols = torch.cat([i + n_user, u])
-    vals = torch.ones(rows.numel(), dtype=torch.float32, device=u.device)
-    rowptr, col, val = coalesce_device(rows, cols, vals, n, n)
-    del rows, cols, vals
-    deg = (rowptr[1:] - rowptr[:-1])
-    rs = deg.to(torch.float32)                       # unit weights: row sum == degree
-    r_of = torch.repeat_interleave(torch.arange(n, device=u.device), deg)
+def _block_device(coo):
+    """(row, col, val | None, (n_r, n_c)) of device tensors; val None = unit entries."""
+    r, c, v, shape = coo
+    r, c = r.to(torch.int64), c.to(torch.int64)
+    if v is None:
+        v = torch.ones(r.numel(), dtype=torch.float32, device=r.device)
+    return r, c, v.to(torch.float32), (int(shape[0]), int(shape[1]))
+
+
+def block_adjacency_device(ui, ut=None, it=None):
+    """`block_adjacency_host` on the GPU (adj.py:7-35): the symmetric [user | item | tag] block adjacency as CSR from COO
+    blocks given as device tensors -- (row, col, val or None, shape); `ut` / `it` hold one entry per (user, item, tag)
+    assignment and repeated pairs are summed into integer weights, as the reference's scipy round trip does
+    (data/tgcn_load.py:21-23).  One sort + segmented sum; nothing visits the host."""
+    r, c, v, (n_u, n_i) = _block_device(ui)
+    rows, cols, vals = [r, c + n_u], [c + n_u, r], [v, v]
+    n = n_u + n_i
+    if ut is not None:
+        r2, c2, v2, (_, n_t) = _block_device(ut)
+        r3, c3, v3, _ = _block_device(it)
+        rows += [r2, c2 + n, r3 + n_u, c3 + n]
+        cols += [c2 + n, r2, c3 + n, r3 + n_u]
+        vals += [v2, v2, v3, v3]
+        n += n_t
+    rowptr, col, val = coalesce_device(torch.cat(rows), torch.cat(cols), torch.cat(vals), n, n)
+    return rowptr, col, val, n
+
+
+def normalise_device(rowptr, col, val, n, norm_type):
+    """`normalise_host` on the GPU (`get_norm_adj`, adj.py:75-110), same fp32 operation order: row sums accumulated in
+    fp64 and rounded once (they are sums of integer weights, so the order of the atomic adds cannot change them),
+    (d[r] * a) * d[c] for bi_norm, d[r] * a for the row-stochastic forms, identity added before (si_norm_self) or after
+    (ngcf) the scaling.  Values agree with the host path to the last bit wherever torch.pow and numpy's power agree
+    (tests allow 1 ulp)."""
+    dev = rowptr.device
+
+    def rows_of(rowptr):
+        return torch.repeat_interleave(torch.arange(n, device=dev), rowptr[1:] - rowptr[:-1])
+
+    def add_eye(rowptr, col, val):
+        eye = torch.arange(n, device=dev)
+        return coalesce_device(torch.cat([rows_of(rowptr), eye]), torch.cat([col.to(torch.int64), eye]),
+                               torch.cat([val, torch.ones(n, dtype=torch.float32, device=dev)]), n, n)
+
+    if norm_type == "si_norm_self":
+        rowptr, col, val = add_eye(rowptr, col, val)
+    if norm_type not in NORM_TYPES:
+        return rowptr, col, val.contiguous()
+    r_of = rows_of(rowptr)
+    rs = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, r_of, val.to(torch.float64)).to(torch.float32)
+    # the power is evaluated in fp64 and rounded once: the correctly rounded fp32 value, which is what numpy's fp32 power
+    # (glibc powf) returns; torch's fp32 pow takes an rsqrt shortcut for -0.5 that can be one ulp off
     if norm_type == "bi_norm":
-        d = torch.pow(rs, -0.5)
+        d = torch.pow(rs.to(torch.float64), -0.5).to(torch.float32)
         d[torch.isinf(d)] = 0.0
         val = (d[r_of] * val) * d[col.long()]
-    elif norm_type in ("si_norm", "ngcf"):
-        d = torch.pow(rs, -1.0)
+    else:
+        d = torch.pow(rs.to(torch.float64), -1.0).to(torch.float32)
         d[torch.isinf(d)] = 0.0
         val = d[r_of] * val
-        if norm_type == "ngcf":
-            eye = torch.arange(n, device=u.device)
-            rowptr, col, val = coalesce_device(torch.cat([r_of, eye]), torch.cat([col.long(), eye]),
-                                               torch.cat([val, torch.ones(n, device=u.device)]), n, n)
-    elif norm_type != "plain":
-        raise ValueError(f"unknown norm_type {norm_type!r}")
-    return rowptr, col, val.contiguous(), n
+    if norm_type == "ngcf":
+        rowptr, col, val = add_eye(rowptr, col, val)
+    return rowptr, col, val.contiguous()
+
+
+def bipartite_norm_device(u, i, n_user, n_item, norm_type="bi_norm"):
+    """User-item adjacency straight on the GPU: u, i int64 tensors of (user, item) pairs.
+    Returns (rowptr, col, val, n).  = `block_adjacency_device` + `normalise_device`."""
+    rowptr, col, val, n = block_adjacency_device((u, i, None, (n_user, n_item)))
+    rowptr, col, val = normalise_device(rowptr, col, val, n, norm_type)
+    return rowptr, col, val, n
 
 
 # ---------------------------------------------------------------------------------- handle

@@ -170,3 +170,54 @@ def test_step_trace_tool_cuts_at_optimizer_bursts(tmp_path):
     table = {row[0]: row for row in __import__("csv").reader(open(out))}
     assert float(table["spmm_rows_kernel"][1]) == 5.0 and int(table["spmm_rows_kernel"][2]) == 2
     assert int(table["tagrec::adam_kernel(float4*)"][2]) == 2
+
+
+def _check_device_adjacency(fx, use_tag, norm, device):
+    """graph.block_adjacency_device + normalise_device (the builder of every synthetic-graph headline number, and the
+    on-device ingest of [E,2] / [A,3] tensors) against the reference's own `creat_adj` output: indices bit for bit,
+    values within 4 ulp.  Why not bit for bit: the reference evaluates d = rowsum ** -0.5 with numpy's fp32 `power`,
+    whose SIMD implementation is itself 1-2 ulp off the correctly rounded value for a quarter of the small integers, and
+    every bi_norm entry multiplies two such factors; the device path rounds the fp64 power once.  (The HOST path,
+    `normalise_host`, calls numpy as the reference does and is bit-exact: test_host_adjacency_bit_exact_vs_reference.)"""
+    ui, ut, it = blocks_from_fixture(fx, use_tag)
+    dev = torch.device(device)
+    t = lambda b: (torch.from_numpy(np.asarray(b[0])).to(dev), torch.from_numpy(np.asarray(b[1])).to(dev), None, b[3])
+    rowptr, col, val, n = G.block_adjacency_device(t(ui), t(ut) if use_tag else None, t(it) if use_tag else None)
+    rowptr, col, val = G.normalise_device(rowptr, col, val, n, norm)
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), rowptr[1:] - rowptr[:-1]).cpu().numpy()
+    want_idx, want_val = fx[f"{norm}_{use_tag}_idx"], fx[f"{norm}_{use_tag}_val"]
+    assert np.array_equal(np.stack([rows, col.cpu().numpy().astype(np.int64)]), want_idx)
+    got = val.cpu().numpy()
+    assert got.dtype == np.float32 and np.all(np.abs(got - want_val) <= 4 * np.spacing(np.abs(want_val)))
+    if not use_tag:                       # the two-block wrapper the benchmarks call
+        rp2, c2, v2, n2 = G.bipartite_norm_device(t(ui)[0], t(ui)[1], ui[3][0], ui[3][1], norm)
+        assert n2 == n and torch.equal(rp2, rowptr) and torch.equal(c2, col) and torch.equal(v2, val)
+
+
+@pytest.mark.parametrize("use_tag", [0, 1])
+@pytest.mark.parametrize("norm", ["bi_norm", "ngcf", "si_norm", "si_norm_self", "plain"])
+def test_device_adjacency_builder_on_cpu_tensors_vs_reference(golden, use_tag, norm):
+    _check_device_adjacency(golden("adj_toy"), use_tag, norm, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_tag", [0, 1])
+@pytest.mark.parametrize("norm", ["bi_norm", "ngcf", "si_norm", "si_norm_self", "plain"])
+def test_device_adjacency_builder_on_gpu_vs_reference(golden, use_tag, norm):
+    _check_device_adjacency(golden("adj_toy"), use_tag, norm, "cuda:0")
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_touching_the_gpu():
+    """`python bench.py --gpus N` starts its own ranks; with fewer GPUs than ranks it must say so and exit non-zero
+    (the parent only counts devices)."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and "one rank per GPU" in line["error"]

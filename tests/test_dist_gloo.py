@@ -29,20 +29,56 @@ class CpuOps:
         dot = torch.where(inv[:, None] >= 1e12, torch.zeros_like(dot), dot)
         return inv[:, None] * (dz - z * dot)
 
-    def spmm_norm_acc(self, g, x, y, inv, acc, s):
-        y.copy_(g @ x)
-        den = y.norm(dim=1).clamp_min(1e-12)
-        inv.copy_(1.0 / den)
-        acc.add_(s * y / den[:, None])
+    # -- row-sharded tables (same contracts as HipOps) ---------------------------------------------
+    row_sparse_backward = True
 
-    def spmm_normbwd(self, g, g_in, x_raw, inv, dz, s, out):
-        out.copy_(g @ g_in + self._nb(x_raw, inv, s * dz))
+    def row_block(self, rowptr, col, val, lo, hi, n_cols):
+        a, b = int(rowptr[lo]), int(rowptr[hi])
+        return torch.sparse_csr_tensor(rowptr[lo:hi + 1] - a, col[a:b].long(), val[a:b], size=(hi - lo, n_cols))
 
-    def spmm_axpy(self, g, g_in, b, s, out):
-        out.copy_(g @ g_in + s * b)
+    def mark_cols(self, g, rows, flags):
+        flags[(g.to_dense() != 0)[rows].any(0)] = 1
+
+    def spmm_listed(self, g, rows, x, out):
+        out.copy_(g.to_dense()[rows] @ x)
+
+    @staticmethod
+    def _keep(row_mask, n):
+        return torch.ones(n, dtype=torch.bool) if row_mask is None else row_mask.bool()
+
+    @staticmethod
+    def _flagged(g_in, in_flags):
+        # rows flagged zero are never read by the kernels (the buffer may hold stale data there)
+        return g_in if in_flags is None else torch.where(in_flags.bool()[:, None], g_in, torch.zeros_like(g_in))
+
+    def layer_fwd(self, g, xf, y, inv, acc, s, row_mask=None):
+        full = g @ xf
+        den = full.norm(dim=1).clamp_min(1e-12)
+        k = self._keep(row_mask, y.shape[0])
+        y[k] = full[k]
+        inv[k] = (1.0 / den)[k]
+        acc[k] += (s * full / den[:, None])[k]
+
+    def layer_bwd(self, g, g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, row_mask=None):
+        res = g @ self._flagged(g_in, in_flags) + self._nb(x_raw, inv, s * dz)
+        k = self._keep(row_mask, out.shape[0])
+        out[k] = res[k]
+        if out_flags is not None:
+            out_flags[k] = (res[k] != 0).any(1).to(torch.uint8)
+
+    def last_hop(self, g, g_in, in_flags, in_count, b, s, out):
+        out.copy_(g @ self._flagged(g_in, in_flags) + s * b)
+
+    def rownorm_fwd(self, x):
+        den = x.norm(dim=1).clamp_min(1e-12)
+        return x / den[:, None], 1.0 / den
 
     def rownorm_bwd(self, x_raw, inv, dz, s, out):
         out.copy_(self._nb(x_raw, inv, s * dz))
+
+    def rownorm_bwd_flags(self, x_raw, inv, dz, s, out):
+        out.copy_(self._nb(x_raw, inv, s * dz))
+        return (out != 0).any(1).to(torch.uint8)
 
     def bpr_fwd(self, U, I, Ur, Ir, trip, kind):
         u, p, n = U[trip[:, 0]], I[trip[:, 1]], I[trip[:, 2]]
@@ -82,6 +118,9 @@ class CpuOps:
         ss[keep] = (full[keep] ** 2).sum(1)
 
     # -- column-sharded tables
+    def spmm_axpy(self, g, g_in, b, s, out):
+        out.copy_(g @ g_in + s * b)
+
     def spmm_ss(self, g, x, y, ss):
         y.copy_(g @ x)
         ss.copy_((y * y).sum(1))
@@ -167,30 +206,39 @@ def test_feature_sharded_lightgcn_matches_single_process(tmp_path, golden, world
     assert np.abs(got["table"] - want_t).max() <= 2e-4
 
 
-def _worker(rank, world, port, out_dir):
-    import sys
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _row_model(rank, world, fx, n_layer, n_chunks, restrict, norm="bi_norm"):
     import tagrec_amd as T
     from tagrec_amd import dist as TD
     from oracle import adj as oadj
+    csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), norm)
+    cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64] * n_layer, reg=float(fx["reg"]), device="cpu",
+                       norm_type=norm)
+    ds = T.synth.Dataset()
+    ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
+    torch.manual_seed(2020)
+    m = TD.ShardedLightGCN(ds, cfg, torch.from_numpy(csr.rowptr), torch.from_numpy(csr.col),
+                           torch.from_numpy(csr.val), csr.shape[0], ops=CpuOps(), n_chunks=n_chunks)
+    m.restrict_forward = restrict
+    m.restrict_min_ratio = 0                  # the toy batches touch most rows: force the restricted step when asked
+    # load the fixture's init so the comparison does not depend on the RNG
+    full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)])
+    with torch.no_grad():
+        m.table.zero_()
+        real_hi = min(m.hi, full.shape[0])
+        if real_hi > m.lo:
+            m.table[:real_hi - m.lo] = full[m.lo:real_hi]
+    return m, csr, full
+
+
+def _worker(rank, world, port, out_dir, n_layer, n_chunks, restrict):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         fx = load_golden("lightgcn_toy")
-        csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "bi_norm")
-        cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64, 64], reg=float(fx["reg"]), device="cpu")
-        ds = T.synth.Dataset()
-        ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
-        torch.manual_seed(2020)
-        m = TD.ShardedLightGCN(ds, cfg, torch.from_numpy(csr.rowptr), torch.from_numpy(csr.col),
-                               torch.from_numpy(csr.val), csr.shape[0], ops=CpuOps())
-        # load the fixture's init so the comparison does not depend on the RNG
-        full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)])
-        with torch.no_grad():
-            m.table.zero_()
-            real_hi = min(m.hi, full.shape[0])
-            m.table[:real_hi - m.lo] = full[m.lo:real_hi]
+        m, csr, full = _row_model(rank, world, fx, n_layer, n_chunks, restrict)
         opt = torch.optim.Adam(m.parameters(), lr=0.01)
         losses = []
         for b in fx["batches"][:3]:
@@ -204,24 +252,105 @@ def _worker(rank, world, port, out_dir):
         table = m.gathered_table()
         u_out, i_out = m.forward()
         if rank == 0:
-            np.savez(os.path.join(out_dir, f"w{world}.npz"), losses=np.array(losses), grad0=grad0.numpy(),
+            np.savez(os.path.join(out_dir, "row.npz"), losses=np.array(losses), grad0=grad0.numpy(),
                      table=table.numpy(), u_out=u_out.numpy(), i_out=i_out.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_lightgcn_matches_single_process(tmp_path, golden, world):
+def _single_process(fx, n_layer):
+    """The same three steps through the CPU oracle (one process, whole table)."""
+    from oracle import adj as oadj, models as om
+    csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "bi_norm")
+    A = om.csr_to_torch(csr)
+    tabs = [torch.from_numpy(fx[f"init.embed.{t}"]).clone().requires_grad_() for t in range(3)]
+    opt = torch.optim.Adam(tabs, lr=0.01)
+    losses, grad0 = [], None
+    for b in fx["batches"][:3]:
+        lossx = om.lightgcn_loss(tabs, A, n_layer, torch.from_numpy(b), float(fx["reg"]), "softplus")
+        losses.append([float(x) for x in lossx])
+        opt.zero_grad()
+        sum(lossx).backward()
+        if grad0 is None:
+            grad0 = torch.cat([t.grad for t in tabs]).numpy().copy()
+        opt.step()
+    with torch.no_grad():
+        nums = [t.shape[0] for t in tabs]
+        outs = torch.split(om.lightgcn_propagate(torch.cat(tabs), A, n_layer), nums, dim=0)
+    return np.array(losses), grad0, torch.cat(tabs).detach().numpy(), outs
+
+
+# (world, layers, row blocks per shard, restricted step): uneven shards (3), every depth the restricted step
+# distinguishes (1: push only, 2: masked + push, 3: full + masked + push), pipelined blocks, and the all-rows step
+@pytest.mark.parametrize("world,n_layer,n_chunks,restrict", [
+    (2, 2, 1, False), (3, 2, 2, False), (2, 2, 1, True), (3, 2, 3, True),
+    (2, 3, 2, True), (2, 1, 1, True), (2, 3, 1, False), (4, 3, 2, True)])
+def test_sharded_lightgcn_matches_single_process(tmp_path, golden, world, n_layer, n_chunks, restrict):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    got = np.load(tmp_path / f"w{world}.npz")
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n_layer, n_chunks, restrict), nprocs=world, join=True)
+    got = np.load(tmp_path / "row.npz")
     fx = golden("lightgcn_toy")
-    np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
-    np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=1e-5)
-    want_g = np.concatenate([fx[f"grad.embed.{t}"] for t in range(3)])
-    np.testing.assert_allclose(got["grad0"], want_g, rtol=1e-3, atol=1e-8)
-    want_t = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
-    assert np.abs(got["table"] - want_t).max() <= 2e-4
+    if n_layer == 2:                                      # the depth the reference fixture was captured at
+        np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
+        np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=1e-5)
+        want_g = np.concatenate([fx[f"grad.embed.{t}"] for t in range(3)])
+        np.testing.assert_allclose(got["grad0"], want_g, rtol=1e-3, atol=1e-8)
+        want_t = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
+        assert np.abs(got["table"] - want_t).max() <= 2e-4
+    losses, grad0, table, outs = _single_process(fx, n_layer)
+    np.testing.assert_allclose(got["losses"], losses, rtol=1e-5)
+    np.testing.assert_allclose(got["grad0"], grad0, rtol=1e-3, atol=1e-8)
+    assert np.abs(got["table"] - table).max() <= 2e-4
+    np.testing.assert_allclose(got["u_out"], outs[0].numpy(), rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(got["i_out"], outs[1].numpy(), rtol=1e-3, atol=2e-4)
+
+
+def _asym_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tagrec_amd._lib import TagrecError
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        fx = load_golden("lightgcn_toy")
+        try:
+            _row_model(rank, world, fx, 2, 1, True, norm="ngcf")
+            msg = "no error"
+        except TagrecError as e:
+            msg = str(e)
+        if rank == 0:
+            with open(os.path.join(out_dir, "msg.txt"), "w") as f:
+                f.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_lightgcn_rejects_asymmetric_normalisation(tmp_path):
+    """D^-1 A + I is not symmetric: the row-sharded backward (pull over A[rows_g, :]) would be silently wrong."""
+    port = _free_port()
+    mp.spawn(_asym_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert "not symmetric" in open(tmp_path / "msg.txt").read()
+
+
+def test_row_partition_layout():
+    from tagrec_amd import dist as TD
+    p = TD.RowPartition(82, 3, 2)                 # 82 nodes, 3 ranks, 2 blocks per shard: Rc = 14, R = 28, padded 84
+    assert (p.rc, p.per, p.n_pad) == (14, 28, 84)
+    ids = torch.arange(84)
+    g = p.gathered(ids)
+    assert sorted(g.tolist()) == list(range(84))  # a permutation
+    # block c of rank h sits at [c*G*Rc + h*Rc, ...): what all_gather_into_tensor of that block writes
+    for h in range(3):
+        for c in range(2):
+            src = ids[h * 28 + c * 14: h * 28 + (c + 1) * 14]
+            assert g[src].tolist() == list(range(c * 42 + h * 14, c * 42 + (h + 1) * 14))
+    assert TD.RowPartition(82, 3, 1).gathered(ids[:82]).tolist() == list(range(82))
+    rp = torch.tensor([0, 2, 2, 5, 6])
+    col = torch.tensor([1, 3, 0, 1, 2, 0], dtype=torch.int32)
+    val = torch.arange(6, dtype=torch.float32)
+    trp, tc, tv = TD.transpose_csr(rp, col, val, 4)
+    dense = torch.sparse_csr_tensor(rp, col.long(), val, size=(4, 4)).to_dense()
+    assert torch.equal(torch.sparse_csr_tensor(trp, tc.long(), tv, size=(4, 4)).to_dense(), dense.t())
 
 
 def test_shard_helpers():

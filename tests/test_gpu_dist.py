@@ -47,7 +47,9 @@ def _worker(rank, world, port, out_dir, kind):
             with torch.no_grad():
                 m.table.copy_(full[:, lo:lo + m.dim_local])
         else:
-            m = TD.ShardedLightGCN(*args)
+            m = TD.ShardedLightGCN(*args, n_chunks=2)
+            if kind == "row_restricted":          # the toy batch touches most rows: force the restricted step
+                m.restrict_min_ratio = 0
             with torch.no_grad():
                 m.table.zero_()
                 hi = min(m.hi, full.shape[0])
@@ -67,7 +69,7 @@ def _worker(rank, world, port, out_dir, kind):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["feature", "row"])
+@pytest.mark.parametrize("kind", ["feature", "row", "row_restricted"])
 def test_two_ranks_real_kernels(tmp_path, golden, kind):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), kind), nprocs=2, join=True)
@@ -77,3 +79,71 @@ def test_two_ranks_real_kernels(tmp_path, golden, kind):
     np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=2e-5)
     want = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
     assert np.abs(got["table"] - want).max() <= 2e-4
+
+
+def _mid_worker(rank, world, port, out_dir, D, n_chunks, n_layer):
+    import sys
+    sys.path.insert(0, ROOT)
+    import tagrec_amd as T
+    from tagrec_amd import dist as TD
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        nu, ni, B = 30_000, 20_000, 128
+        ds = T.synth.make_bipartite_device(nu, ni, 1_500_000, seed=3, device=dev)      # same seed -> same graph on both ranks
+        e = ds.edge_index["train"]
+        rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], nu, ni, "bi_norm")
+        cfg = T.get_config("lightgcn", use_tag=False, dim_latent=D, dim_layer_list=[D] * n_layer, device=dev, train_batch=B, reg=1e-3)
+        torch.manual_seed(2)
+        ref = T.LightGCN(ds, config=cfg, graph=T.Graph(rp, col, val, (n, n), symmetric=True))
+        ref.train()
+        ref.restrict_forward = False                   # the reference point: every layer on all rows, one GPU
+        sm = TD.ShardedLightGCN(ds, cfg, rp, col, val, n, n_chunks=n_chunks)
+        assert 3 * B * sm.restrict_min_ratio <= n       # the restricted sharded step is what runs
+        with torch.no_grad():
+            sm.table.zero_()
+            hi = min(sm.hi, n)
+            sm.table[:hi - sm.lo] = ref.table[sm.lo:hi]
+        batches = T.BPR_training_data(ds, config=cfg, seed=1).all_train_data
+        o1, o2 = T.Adam(ref.parameters(), lr=0.01), T.Adam(sm.parameters(), lr=0.01)
+        rec = {}
+        u, i = sm.forward()                            # evaluation path: every layer on all rows, gathered tables
+        ref.eval()
+        with torch.no_grad():
+            ru, ri = ref.forward()
+        ref.train()
+        rec["u1"], rec["u2"], rec["i1"], rec["i2"] = ru.cpu().numpy(), u.cpu().numpy(), ri.cpu().numpy(), i.cpu().numpy()
+        for step in range(2):
+            b = batches[step * B:(step + 1) * B]
+            l1, l2 = ref.loss(b), sm.loss(b)
+            o1.zero_grad(); o2.zero_grad()
+            sum(l1).backward(); sum(l2).backward()
+            rec[f"l1_{step}"] = np.array([float(v) for v in l1]); rec[f"l2_{step}"] = np.array([float(v) for v in l2])
+            rec[f"g1_{step}"] = ref.table.grad.cpu().numpy()
+            rec[f"g2_{step}"] = sm.all_gather(sm.table.grad)[:n].cpu().numpy()
+            o1.step(); o2.step()
+        rec["t1"], rec["t2"] = ref.table.detach().cpu().numpy(), sm.gathered_table().cpu().numpy()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "mid.npz"), **rec)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("D,n_chunks,n_layer", [(64, 2, 3), (256, 3, 3), (64, 1, 2)])
+def test_row_sharded_restricted_step_equals_single_gpu_model(tmp_path, D, n_chunks, n_layer):
+    """Two ranks (both on cuda:0, exchanging through gloo), real kernels, a graph large enough for the restricted sharded
+    step (pipelined block all-gathers, masked layer, push-form top layer, flagged gradient tables): losses, table
+    gradients, tables after two Adam steps and the propagated tables of the one-GPU model computed on ALL rows.
+    D = 256 is the C5 row width."""
+    port = _free_port()
+    mp.spawn(_mid_worker, args=(2, port, str(tmp_path), D, n_chunks, n_layer), nprocs=2, join=True)
+    r = np.load(tmp_path / "mid.npz")
+    for step in range(2):
+        np.testing.assert_allclose(r[f"l2_{step}"], r[f"l1_{step}"], rtol=5e-6)
+        g1, g2 = r[f"g1_{step}"], r[f"g2_{step}"]
+        np.testing.assert_allclose(g2, g1, rtol=1e-4, atol=2e-6 * np.abs(g1).max())
+    # Adam turns last-bit gradient differences of near-zero entries into lr-sized steps (DESIGN.md section 2)
+    assert np.abs(r["t2"] - r["t1"]).max() <= 2e-4 * 2
+    np.testing.assert_allclose(r["u2"], r["u1"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r["i2"], r["i1"], rtol=1e-4, atol=1e-5)

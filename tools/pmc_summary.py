@@ -57,8 +57,17 @@ def main():
                      "hbm_side_bytes_per_launch(2*FETCH+WRITE)*1024", "mean_ms_under_pmc"])
         for r in rows:
             wr.writerow([r[0], r[1], f"{r[2]:.1f}", f"{r[3]:.1f}", f"{r[4]:.0f}", f"{r[5]:.0f}", f"{r[6]:.0f}", f"{r[7]:.4f}"])
+    import datetime
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("spmm.hip", "graph.h", "common.h"):
+        with open(os.path.join(root, "tag-aware-recommendation_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
     with open(out + ".json", "w") as fh:
-        json.dump({"source": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum TCC_MISS_sum> --kernel-trace, three separate passes of `"
+        json.dump({"command": cmd, "collected": datetime.date.today().isoformat(), "head": os.environ.get("GRAFT_HEAD", "?"),
+                   "kernel_source_sha16": h.hexdigest()[:16],
+                   "source": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum TCC_MISS_sum> --kernel-trace, three separate passes of `"
                              + cmd + "` (1 MI355X)",
                    "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> doubled; WRITE_SIZE exact (check both on adam_kernel: "
                                  "16 B read and 12 B written per parameter element)",
