@@ -379,6 +379,7 @@ class _ShardedLoss(torch.autograd.Function):
         d_out = torch.zeros(ctx.shape, dtype=torch.float32, device=dev)    # gradient w.r.t. `out`, local rows
         d_out.index_add_(0, ctx.loc, d_b[0][ctx.slot])
         n_pull = len(raws)
+        head_rows = None
         # ---- head of the chain: G^L, either on the batch rows (restricted) or on the local rows
         if L == 0:
             g0 = d_out
@@ -387,15 +388,17 @@ class _ShardedLoss(torch.autograd.Function):
                 g_top = torch.empty(T, D, dtype=torch.float32, device=dev)
                 ops.rownorm_bwd(ctx.y_top, ctx.inv_top, d_b[0], s, g_top)
                 # the operand of the next product: zero except at the batch rows (slots naming one node are summed)
-                gfull = m._scratch(("bwd", D, 0), (part.n_pad, D), torch.float32)
-                gfull.index_fill_(0, ctx.rows_p, 0.0)
+                # (the buffer is all-zero between steps: a product that decides to ignore the row flags -- they cover
+                # more than 4/5 of the rows -- must still read zeros there)
+                gfull = m._scratch(("bwd", D, 0), (part.n_pad, D), torch.float32, zero=True)
                 gfull.index_add_(0, ctx.rows_p, g_top)
                 flags = torch.zeros(part.n_pad, dtype=torch.uint8, device=dev)
                 flags.index_fill_(0, ctx.rows_p, 1)
                 count = torch.full((1,), T, dtype=torch.int32, device=dev)
-                operand = (gfull, flags if sparse else None, count if sparse else None)
                 if not sparse:
                     raise _lib.TagrecError("restricted sharded step needs the row-flag kernels")
+                operand = (gfull, flags, count)
+                head_rows = ctx.rows_p
             else:
                 gl = torch.empty_like(d_out)
                 fl = ops.rownorm_bwd_flags(raws[L - 1], invs[L - 1], d_out, s, gl) if sparse else None
@@ -416,11 +419,16 @@ class _ShardedLoss(torch.autograd.Function):
                     ops.layer_bwd(m.graph_chunks[c], operand[0], operand[1], operand[2], raws[k][r], invs[k][r], d_out[r], s,
                                   gn[r], fo[r] if sparse else None, ctx.mid_mask[r] if masked else None)
                     gat.put(c, gn[r], fo[r] if sparse else None)
+                if head_rows is not None:                      # the batch-row operand has been consumed: back to all-zero
+                    operand[0].index_fill_(0, head_rows, 0.0)
+                    head_rows = None
                 operand = gat.result()
             g0 = torch.empty_like(d_out)
             for c in range(part.n_chunks):
                 r = part.chunk_rows(c)
                 ops.last_hop(m.graph_chunks[c], operand[0], operand[1], operand[2], d_out[r], s, g0[r])
+            if head_rows is not None:
+                operand[0].index_fill_(0, head_rows, 0.0)
         g0.index_add_(0, ctx.loc, d_b[1][ctx.slot])                      # L2 term on the ego rows this rank owns
         ctx.raws = ctx.invs = ctx.y_top = None
         return g0, None, None
@@ -506,10 +514,10 @@ class ShardedLightGCN(torch.nn.Module):
         self.comm_bytes = 0
 
     # -- scratch: gathered tables are reused from step to step (no 512 MB allocations inside the step) -------------
-    def _scratch(self, key, shape, dtype):
+    def _scratch(self, key, shape, dtype, zero=False):
         t = self._buffers_cache.get(key)
         if t is None or tuple(t.shape) != tuple(shape):
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self._buffers_cache[key] = t
         return t
 

@@ -48,8 +48,9 @@ class CpuOps:
 
     @staticmethod
     def _flagged(g_in, in_flags):
-        # rows flagged zero are never read by the kernels (the buffer may hold stale data there)
-        return g_in if in_flags is None else torch.where(in_flags.bool()[:, None], g_in, torch.zeros_like(g_in))
+        # the kernels MAY skip rows flagged zero and MAY read them (they stop consulting the flags once these cover 4/5
+        # of the rows): the caller must keep such rows zero.  Reading everything here checks that it does.
+        return g_in
 
     def layer_fwd(self, g, xf, y, inv, acc, s, row_mask=None):
         full = g @ xf
