@@ -52,7 +52,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--big-batch", type=int, default=786432, help="also report triplets/s at this batch (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="timed steps of the CPU baseline (after one warm-up step)")
+    ap.add_argument("--cpu-steps", type=int, default=1,
+                    help="timed steps of the CPU baseline on the full workload graph (a C2 step takes the 16 host threads "
+                         "about 70 s; with more than one step a warm-up step runs first)")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--force-shard", action="store_true",
@@ -140,7 +142,8 @@ def cpu_baseline(args, model_kind, rp, col, val, n, nu, ni, epoch):
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))   # the box gives a one-GPU job a 16-core share of the host
     torch.set_num_threads(cores)
     D, L, B = args.dim, args.layers, args.batch
-    n_warm, n_timed = 1, max(1, args.cpu_steps)
+    n_timed = max(1, args.cpu_steps)
+    n_warm = 1 if n_timed > 1 else 0        # a step is ~10^2 s of sparse products: first-call effects are far below 1 %
     print(f"[bench] cpu_baseline: {model_kind} oracle on the full graph (nnz={int(rp[-1])}), {n_warm}+{n_timed} steps, "
           f"{cores} threads ...", file=sys.stderr, flush=True)
     A = om.csr_to_torch(oadj.CSR(rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(), (n, n)))
@@ -158,7 +161,8 @@ def cpu_baseline(args, model_kind, rp, col, val, n, nu, ni, epoch):
     return {"value": B / dt, "unit": "triplets/s", "cores": cores, "kind": "port", "ms_per_step": dt * 1e3,
             "sample": f"CPU oracle (torch {torch.__version__} CPU ops, {cores} threads), {name} L={L} D={D} B={B} on the FULL "
                       f"workload graph ({nu} x {ni}, nnz={int(rp[-1])}): {dt:.2f} s/step measured over {n_timed} steps after "
-                      f"{n_warm} warm-up step; no scaling applied"}
+                      f"{n_warm} warm-up step(s); no scaling applied (the 1+3-step run of the same leg is kept in "
+                      f"profiles/r02_bench_c2_cpu3.log)"}
 
 
 def bench_tgcn(args):

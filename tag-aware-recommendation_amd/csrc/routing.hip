@@ -502,7 +502,7 @@ extern "C" int tagrec_route_rowsum_rsqrt_f32(const tagrec_graph* g, const float*
     LongView lv;
     int rc = long_view(g, KK, &lv);
     if (rc != TAGREC_OK) return rc;
-    const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+    const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
     const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
     route_rowsum_kernel<KK><<<blocks + lv.chunk_blocks, kWavesPerBlock * kWave, 0, s>>>(gv, w, d, lv);
     TAGREC_LAUNCH_CHECK();
@@ -553,7 +553,7 @@ extern "C" int tagrec_route_spmm_ex_f32(const tagrec_graph* g, const float* W, i
     LongView lv;
     int rc = long_view(g, LPR * 4, &lv);
     if (rc != TAGREC_OK) return rc;
-    const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+    const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
     const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
     route_spmm_kernel<LPR, KK><<<blocks + lv.chunk_blocks, kWavesPerBlock * kWave, 0, s>>>(gv, W, X, e, lv);
     TAGREC_LAUNCH_CHECK();
@@ -582,7 +582,7 @@ extern "C" int tagrec_route_score_rows_f32(const tagrec_graph* g, const float* H
     constexpr int LPR = decltype(lc)::value, KK = decltype(kc)::value;
     LongView lv{g->long_rows, g->chunk_desc, g->n_chunks, nullptr,
                 g->n_long > 0 ? static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock) : 0u};
-    const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+    const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
     const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
     route_score_kernel<LPR, KK><<<blocks + lv.chunk_blocks, kWavesPerBlock * kWave, 0, s>>>(gv, H, T, logits, accumulate, lv, row_mask);
     TAGREC_LAUNCH_CHECK();
@@ -630,7 +630,7 @@ extern "C" int tagrec_row_softmax_fwd_f32(const tagrec_graph* g, const float* lo
   TAGREC_REQUIRE(g, "row_softmax_fwd: null graph");
   TAGREC_REQUIRE(g->nnz == 0 || (logits && a), "row_softmax_fwd: null pointer");
   if (g->n_rows == 0 || g->nnz == 0) return TAGREC_OK;
-  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
   row_softmax_fwd_kernel<<<blocks, kWavesPerBlock * kWave, 0, static_cast<hipStream_t>(stream)>>>(gv, logits, a);
   TAGREC_LAUNCH_CHECK();
@@ -641,7 +641,7 @@ extern "C" int tagrec_row_softmax_bwd_f32(const tagrec_graph* g, const float* a,
   TAGREC_REQUIRE(g, "row_softmax_bwd: null graph");
   TAGREC_REQUIRE(g->nnz == 0 || (a && da && dlogits), "row_softmax_bwd: null pointer");
   if (g->n_rows == 0 || g->nnz == 0) return TAGREC_OK;
-  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
   row_softmax_bwd_kernel<<<blocks, kWavesPerBlock * kWave, 0, static_cast<hipStream_t>(stream)>>>(gv, a, da, dlogits);
   TAGREC_LAUNCH_CHECK();

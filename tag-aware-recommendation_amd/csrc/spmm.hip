@@ -536,7 +536,7 @@ namespace {
 
 template <int LPR, int EPI>
 int launch_vec(const tagrec_graph* g, const float* X, const EpiArgs& e, hipStream_t s) {
-  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   const int threads = kWavesPerBlock * kWave;
   const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
   LongView lv{g->long_rows, g->chunk_desc, g->n_chunks, nullptr, 0};
@@ -595,7 +595,7 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
                                                      "every operand 16-byte aligned); the scalar kernel would ignore them");
   if (D > kMaxGenericBlocks * kWave)
     return fail(TAGREC_E_UNSUPPORTED, std::string(who) + ": row width " + std::to_string(D) + " > 512 is not covered");
-  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
   spmm_rows_generic_kernel<EPI><<<blocks, kWavesPerBlock * kWave, 0, s>>>(gv, X, e, D);
   TAGREC_LAUNCH_CHECK();
@@ -716,7 +716,7 @@ extern "C" int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* r
   TAGREC_REQUIRE(g->n_rows == g->n_cols, "graph_mark_rows: square adjacency expected (flags are indexed by node)");
   TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "graph_mark_rows: bad row count");
   if (n_listed == 0) return TAGREC_OK;
-  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   mark_rows_kernel<true><<<static_cast<unsigned>(n_listed), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
@@ -727,7 +727,7 @@ extern "C" int tagrec_graph_mark_cols_u8(const tagrec_graph* g, const int64_t* r
   TAGREC_REQUIRE(g != nullptr && flags != nullptr && (n_listed == 0 || rows != nullptr), "graph_mark_cols: null pointer");
   TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "graph_mark_cols: bad row count");
   if (n_listed == 0) return TAGREC_OK;
-  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   mark_rows_kernel<false><<<static_cast<unsigned>(n_listed), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
@@ -739,7 +739,7 @@ extern "C" int tagrec_spmm_listed_f32(const tagrec_graph* g, const int64_t* rows
   TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "spmm_listed: bad row count");
   TAGREC_REQUIRE(aligned16(X) && aligned16(Y), "spmm_listed: rows must be 16-byte aligned");
   if (n_listed == 0) return TAGREC_OK;
-  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val};
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned blocks = static_cast<unsigned>(n_listed);
   const int threads = kWavesPerBlock * kWave;

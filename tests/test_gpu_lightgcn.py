@@ -458,3 +458,37 @@ def test_row_flags_kernel(D):
     flags, count = TD.HipOps().row_flags(x.to(DEV))
     want = (x != 0).any(dim=1)
     assert torch.equal(flags.cpu().bool(), want) and int(count) == int(want.sum()) == 777
+
+
+@pytest.mark.parametrize("shape", [(3000, 3000), (500, 40_000)])
+def test_flagged_zero_rows_are_not_fetched(shape):
+    """The row-flag contract of the backward products (include/tagrec.h, "ROW-SPARSE gradient"): while the flags cover less
+    than 4/5 of the operand's rows, rows flagged zero are not read at all -- here they hold NaN, which any read would
+    propagate.  The rectangular case is a row shard (few local rows, flags over the whole gathered table): the 4/5 rule is
+    counted against the operand's rows, not the local ones.  Once the flags cover most rows they are ignored and the same
+    call must read everything (operand cleaned first)."""
+    n_r, n_c = shape
+    gen = torch.Generator().manual_seed(n_c)
+    deg = torch.randint(1, 40, (n_r,), generator=gen)
+    deg[7] = 2500                                                   # one long row (chunked path)
+    rp = torch.zeros(n_r + 1, dtype=torch.int64)
+    torch.cumsum(deg, 0, out=rp[1:])
+    col = torch.cat([torch.randperm(n_c, generator=gen)[:d].sort().values for d in deg.tolist()]).to(torch.int32)
+    val = torch.rand(col.numel(), generator=gen) + 0.5
+    g = T.Graph(rp.to(DEV), col.to(DEV), val.to(DEV), (n_r, n_c))
+    D = 64
+    for frac in (0.05, 0.95):
+        keep = torch.rand(n_c, generator=gen) < frac
+        x = torch.randn(n_c, D, generator=gen) * keep[:, None]
+        b = torch.randn(n_r, D, generator=gen)
+        want = (torch.sparse_csr_tensor(rp, col.long(), val.double(), size=shape) @ x.double() + 0.5 * b.double()).float()
+        xd = x.clone()
+        if frac < 0.8:
+            xd[~keep] = float("nan")                                # must never be fetched
+        flags = keep.to(torch.uint8).to(DEV)
+        count = flags.sum(dtype=torch.int32).reshape(1)
+        out = torch.empty(n_r, D, device=DEV)
+        g.spmm_axpy_sparse(xd.to(DEV), flags, count, b.to(DEV), 0.5, out)
+        got = out.cpu()
+        assert torch.isfinite(got).all(), "a row flagged zero was fetched"
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
