@@ -312,6 +312,11 @@ def main(only=None):
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
         print("wrote", name, {k: v for k, v in fx.items() if np.ndim(v) == 0})
 
+    if only in (None, "d256"):
+        # C5's row width (dim 256, 3 layers) on the toy graph: the widest vector kernel, forward / loss / grads / Adam
+        model_case("lightgcn_toy_d256", toy, "lightgcn", True, (256, 256, 256), 256, 1e-3, 64, 16)
+        if only == "d256":
+            return
     model_case("lightgcn_toy", toy, "lightgcn", True, (64, 64), 64, 1e-3, 64, 11)
     model_case("lightgcn_med", med, "lightgcn", False, (64, 64, 64), 64, 0.0, 512, 12)
     model_case("lightgcn_toy_d32", toy, "lightgcn", False, (32,), 32, 1e-2, 48, 13)

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, kind):
+def _worker(rank, world, port, out_dir, kind, fixture="lightgcn_toy"):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -33,9 +33,10 @@ def _worker(rank, world, port, out_dir, kind):
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        fx = load_golden("lightgcn_toy")
+        fx = load_golden(fixture)
         csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "bi_norm")
-        cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64, 64], reg=float(fx["reg"]), device=dev)
+        cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[int(x) for x in fx["layers"]], dim_latent=int(fx["D"]),
+                           reg=float(fx["reg"]), device=dev)
         ds = T.synth.Dataset()
         ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
         args = (ds, cfg, torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.col).to(dev), torch.from_numpy(csr.val).to(dev),
@@ -69,12 +70,16 @@ def _worker(rank, world, port, out_dir, kind):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["feature", "row", "row_restricted"])
-def test_two_ranks_real_kernels(tmp_path, golden, kind):
+@pytest.mark.parametrize("kind,fixture", [("feature", "lightgcn_toy"), ("row", "lightgcn_toy"), ("row_restricted", "lightgcn_toy"),
+                                          ("row_restricted", "lightgcn_toy_d256"), ("row", "lightgcn_toy_d256"),
+                                          ("feature", "lightgcn_toy_d256")])
+def test_two_ranks_real_kernels(tmp_path, golden, kind, fixture):
+    """Three Adam steps on two ranks against the parameters the REFERENCE reached (golden `step3`); the d256 fixture is
+    C5's row width (3 layers), where the restricted row-sharded step uses all of: full layer, masked layer, push-form top."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), kind), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), kind, fixture), nprocs=2, join=True)
     got = np.load(tmp_path / f"{kind}.npz")
-    fx = golden("lightgcn_toy")
+    fx = golden(fixture)
     np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
     np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=2e-5)
     want = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])

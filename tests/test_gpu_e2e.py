@@ -160,6 +160,75 @@ def test_c2_fused_layer_consistent_with_plain_spmm(c2_graph):
     np.testing.assert_allclose(inv.cpu().numpy(), (1.0 / plain.norm(dim=1).clamp_min(1e-12)).cpu().numpy(), rtol=1e-5)
 
 
+@pytest.fixture(scope="module")
+def c3_graph(c2_graph):
+    """C3 = the C2 graph under NGCF's normalisation D^-1 A + I (adj.py:82-83): not symmetric, so the backward multiplies by
+    the transposed CSR built by Graph.transpose()."""
+    _, e = c2_graph
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 1_000_000, 1_000_000, "ngcf")
+    return T.Graph(rp, col, val, (n, n))
+
+
+def test_c3_transposed_graph_properties(c3_graph):
+    """Full-size transposed 102 M-entry CSR: <A x, y> = <x, A^T y>, rows of A sum to 2 (D^-1 A is row-stochastic, + I),
+    sampled rows of A^T y (the most popular columns included) against an fp64 sum over the matrix's own entries."""
+    g = c3_graph
+    gt = g.transpose()
+    n, D = g.shape[0], 64
+    assert g.nnz == 102_000_000 and gt.nnz == g.nnz and gt.shape == g.shape and not g.symmetric
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, D, device=DEV, generator=gen)
+    y = torch.randn(n, D, device=DEV, generator=gen)
+    ax, aty = g.spmm(x), gt.spmm(y)
+    lhs, rhs = float((ax.double() * y.double()).sum()), float((x.double() * aty.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * (abs(lhs) + abs(rhs)) + 1e-3
+    ones = g.spmm(torch.ones(n, 8, device=DEV))
+    assert float((ones - 2.0).abs().max()) <= 1e-4
+    deg_t = gt.rowptr[1:] - gt.rowptr[:-1]
+    rows = torch.cat([torch.randint(0, n, (40,), device=DEV, generator=gen), torch.topk(deg_t, 2).indices])
+    row_of = None
+    for r in rows.tolist():
+        idx = torch.nonzero(g.col == r).flatten()                       # entries of column r of A = row r of A^T
+        src = torch.searchsorted(g.rowptr, idx, right=True) - 1
+        want = (g.val[idx, None].double() * y[src].double()).sum(0)
+        np.testing.assert_allclose(aty[r].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+        assert int(deg_t[r]) == idx.numel()
+
+
+def test_c3_restricted_ngcf_step_equals_all_rows_step(c2_graph, c3_graph):
+    """One NGCF training step at the full C3 size: the restricted step (top two layers' neighbour sums on the rows the
+    loss depends on, top dense block on the batch rows, row-sparse backward through the transposed CSR) must give the
+    loss and the gradients of the step that computes every layer on all rows."""
+    from tagrec_amd import ngcf as NG
+    _, e = c2_graph
+    nu = ni = 1_000_000
+    ds = T.synth.Dataset()
+    ds.num = {"user": nu, "item": ni}
+    cfg = T.get_config("ngcf", use_tag=False, dim_latent=64, dim_layer_list=[64, 64, 64], device=DEV, train_batch=512)
+    torch.manual_seed(4)
+    m = T.NGCF(ds, config=cfg, graph=c3_graph)
+    m.train()
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    pick = torch.randint(0, e.shape[0], (512,), device=DEV, generator=gen)
+    batch = torch.stack([e[pick, 0], e[pick, 1], torch.randint(0, ni, (512,), device=DEV, generator=gen)], 1)
+    res = []
+    for restrict in (True, False):
+        NG.RESTRICT_FORWARD = restrict
+        try:
+            m.zero_grad()
+            lossx = m.loss(batch)
+            sum(lossx).backward()
+            res.append(([float(v) for v in lossx], {k: p.grad.clone() for k, p in m.named_parameters()}))
+        finally:
+            NG.RESTRICT_FORWARD = True
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
+    for k, want in res[1][1].items():
+        got = res[0][1][k]
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 1e-3 * scale + 1e-12, k
+        assert float(want.abs().max()) > 0
+
+
 @pytest.mark.parametrize("D,n_user,n_item,K", [(64, 300, 1000, 20), (256, 130, 515, 20), (16, 70, 33, 10), (192, 64, 200, 5)])
 def test_fused_eval_topk_matches_torch_path(D, n_user, n_item, K):
     """csrc/eval.hip (score -> mask -> top-K in one pass) against sigmoid(U I^T) + mask + torch.topk."""

@@ -138,7 +138,7 @@ def test_spmm_rejects_bad_arguments():
 
 
 # ------------------------------------------------------------------ fused layers vs golden
-@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d32"])
+@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d32", "lightgcn_toy_d256"])
 def test_lightgcn_forward_golden(golden, name):
     fx = golden(name)
     m = _model(fx)
@@ -154,7 +154,7 @@ def test_lightgcn_forward_golden(golden, name):
         np.testing.assert_allclose(x.cpu().numpy(), fx[f"raw.{k}"], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d32"])
+@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d32", "lightgcn_toy_d256"])
 def test_lightgcn_loss_and_grads_golden(golden, name):
     fx = golden(name)
     m = _model(fx)
@@ -168,7 +168,7 @@ def test_lightgcn_loss_and_grads_golden(golden, name):
 
 
 @pytest.mark.parametrize("fused_opt", [True, False])
-@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med"])
+@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d256"])
 def test_lightgcn_adam_steps_golden(golden, name, fused_opt):
     fx = golden(name)
     for n_steps in (1, 3):

@@ -249,6 +249,69 @@ def test_c4_size_kernels_on_sampled_nodes():
     np.testing.assert_allclose(got[pick].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=3e-5)
 
 
+def test_c4_size_fused_backward_kernels_vs_oracle():
+    """`tgcn_fuse_bwd` / `tgcn_fuse_wf` at the C4 launch size (1 M nodes of one type, D = Dout = 128) against the ORACLE's
+    `tgcn_atten2` + `tgcn_conv` + fusion layer (oracle/models.py, fp64) on sampled nodes.  The block is row-local, so
+    (a) the input gradients of a sampled node depend on that node alone, and (b) a weight gradient is a sum of per-node
+    terms, linear in the upstream gradient: W(up) - W(up with the sampled rows zeroed) is the sampled nodes' share, which
+    the oracle can evaluate.  Both launches are full size (the upstream gradient is dense, so no rows are dropped)."""
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    n, D, A, C, V = 1_000_000, 128, 32, 32, 8
+    r = lambda *s, sc=1.0: torch.randn(*s, device=DEV, generator=gen) * sc
+    ts = [r(n, D, sc=0.5) for _ in range(3)]
+    prm = [r(D, A, sc=0.2), r(1, A, sc=0.1), r(1, A), r(C, 1, 3, 1, sc=0.5), r(V, 1, 1, D, sc=0.2), r(V, 1, 2, D, sc=0.2),
+           r(V, 1, 3, D, sc=0.2), r(C * D + 6 * V, D, sc=0.05), r(1, D, sc=0.1)]
+    names = ["U", "q", "p", "conv.bit_level.weight", "conv.vec_level.conv_1.weight", "conv.vec_level.conv_2.weight",
+             "conv.vec_level.conv_3.weight", "Wf", "bf"]
+    up = r(n, D)
+    pick = torch.unique(torch.randint(0, n, (1500,), device=DEV, generator=gen))
+
+    def oracle(idx):
+        P = {"l." + k: v.detach().double().cpu().requires_grad_() for k, v in zip(names, prm)}
+        t = [x[idx].double().cpu().requires_grad_() for x in ts]
+        e3 = om.tgcn_atten2(P, "l.", *t)
+        pre_bit = torch.einsum("cj,njd->ncd", P["l.conv.bit_level.weight"][:, 0, :, 0], e3)
+        S = torch.stack(t, 1) @ P["l.U"] + P["l.q"]
+        amb = (pre_bit.abs().amin(dim=(1, 2)) < 2e-7) | (S.abs().amin(dim=(1, 2)) < 2e-7)     # ReLU kinks (see above)
+        out = torch.relu(om.tgcn_conv(P, "l.", e3) @ P["l.Wf"] + P["l.bf"])
+        return P, t, out, amb
+
+    with torch.no_grad():
+        _, _, _, amb = oracle(pick)
+    pick = pick[~amb.to(DEV)]
+    assert pick.numel() >= 1200
+
+    def run(up_):
+        leaves = [x.clone().requires_grad_() for x in ts]
+        ps = [x.clone().requires_grad_() for x in prm]
+        U, q, p, wb, w1, w2, w3, Wf, bf = ps
+        out = TG._FusedDense.apply(leaves[0], leaves[1], leaves[2], U, q.reshape(-1), p.reshape(-1), wb.reshape(C, 3),
+                                   w1.reshape(V, -1), w2.reshape(V, -1), w3.reshape(V, -1), Wf, bf.reshape(-1), 65536)
+        TG.timing = {}
+        (out * up_).sum().backward()
+        launched = {k: len(v) for k, v in TG.timing.items()}
+        TG.timing = None
+        assert launched.get("fuse_bwd") == 1 and launched.get("fuse_wf") == 1        # one full-size launch each
+        return out.detach(), [x.grad for x in leaves], [x.grad for x in ps]
+
+    out, dts, dps = run(up)
+    up0 = up.clone()
+    up0[pick] = 0.0
+    _, _, dps0 = run(up0)
+    P, t, want_out, _ = oracle(pick)
+    (want_out * up[pick].double().cpu()).sum().backward()
+    np.testing.assert_allclose(out[pick].cpu().numpy(), want_out.detach().float().numpy(), rtol=1e-4, atol=3e-5)
+    scale = max(float(x.grad.abs().max()) for x in t)
+    for k in range(3):                                               # (a) input gradients, row-local
+        _close(dts[k][pick].cpu().numpy(), t[k].grad.float().numpy(), f"d t{k}", rtol=2e-3, scale=scale)
+    for name, a, b in zip(names, dps, dps0):                         # (b) weight gradients: the sampled nodes' share
+        want = P["l." + name].grad.float().numpy().reshape(a.shape)
+        got = (a.double() - b.double()).float().cpu().numpy()
+        # the two full sums run over 1e6 nodes in fp32: their difference carries ~1e-4 of the FULL sum's magnitude
+        floor = 2e-4 * float(a.abs().max()) + 1e-6
+        assert np.all(np.abs(got - want) <= 2e-2 * np.abs(want) + floor + 2e-3 * np.abs(want).max()), name
+
+
 def test_fused_dense_backward_drops_zero_gradient_rows():
     """`_FusedDense.backward` runs its kernels on the rows with a non-zero upstream gradient only (the batch rows / their
     sampled neighbours) and scatters the result back: same gradients as the all-rows pass."""

@@ -60,7 +60,7 @@ def _adj(fx):
     return om.csr_to_torch(csr)
 
 
-@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d32"])
+@pytest.mark.parametrize("name", ["lightgcn_toy", "lightgcn_med", "lightgcn_toy_d32", "lightgcn_toy_d256"])
 def test_lightgcn_oracle(golden, name):
     fx = golden(name)
     A, L = _adj(fx), len(fx["layers"])
