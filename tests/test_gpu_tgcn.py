@@ -272,14 +272,21 @@ def test_c4_size_fused_backward_kernels_vs_oracle():
         e3 = om.tgcn_atten2(P, "l.", *t)
         pre_bit = torch.einsum("cj,njd->ncd", P["l.conv.bit_level.weight"][:, 0, :, 0], e3)
         S = torch.stack(t, 1) @ P["l.U"] + P["l.q"]
-        amb = (pre_bit.abs().amin(dim=(1, 2)) < 2e-7) | (S.abs().amin(dim=(1, 2)) < 2e-7)     # ReLU kinks (see above)
-        out = torch.relu(om.tgcn_conv(P, "l.", e3) @ P["l.Wf"] + P["l.bf"])
-        return P, t, out, amb
+        # ReLU kinks (see test_fused_dense_block_vs_operator_form): the fp32 kernel's e3 differs from the fp64 one by ~1e-6
+        # relative, so a bit-level pre-activation of 2.5e-7 (met in this sample) lands on the other side of 0
+        amb = (pre_bit.abs().amin(dim=(1, 2)) < 2e-6) | (S.abs().amin(dim=(1, 2)) < 1e-5)
+        for j in (1, 2, 3):                                              # vector-level pre-activations: D- to 3D-term sums
+            w = P[f"l.conv.vec_level.conv_{j}.weight"][:, 0]
+            win = torch.stack([e3[:, h:h + j, :] for h in range(4 - j)], dim=1)
+            amb |= torch.einsum("cad,nhad->nch", w, win).abs().amin(dim=(1, 2)) < 1e-5
+        pre_out = om.tgcn_conv(P, "l.", e3) @ P["l.Wf"] + P["l.bf"]       # 4144-term fp32 sums: rounding ~1e-5
+        amb |= pre_out.abs().amin(dim=1) < 5e-5
+        return P, t, torch.relu(pre_out), amb
 
     with torch.no_grad():
         _, _, _, amb = oracle(pick)
     pick = pick[~amb.to(DEV)]
-    assert pick.numel() >= 1200
+    assert pick.numel() >= 700
 
     def run(up_):
         leaves = [x.clone().requires_grad_() for x in ts]
