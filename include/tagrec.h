@@ -40,7 +40,7 @@ extern "C" {
 #define TAGREC_LOSS_SOFTPLUS 0    /* mean softplus(neg - pos)        (loss.py:11) */
 #define TAGREC_LOSS_LOGSIGMOID 1  /* -mean logsigmoid(pos - neg)     (loss.py:9)  */
 
-#define TAGREC_ABI_VERSION 1
+#define TAGREC_ABI_VERSION 2
 
 typedef struct tagrec_graph tagrec_graph;
 
@@ -106,30 +106,39 @@ int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t 
 /* Backward layers on a ROW-SPARSE gradient.  The gradient that enters the backward chain is non-zero on the <= 3 B rows
  * of the batch only, and one hop later on their neighbours, so most rows a backward product would gather are zero.
  * row_flags[c] (uint8) != 0 iff row c holds a non-zero; *count (uint32, device) = how many rows are flagged.  A product
- * given in_flags / in_count does not fetch rows flagged zero -- the result is bit-identical, a x 0 adds exactly 0 -- and
- * consults the flags only while they cover less than 4/5 of the rows (decided on the device, no host read).
+ * given in_flags / in_count does not fetch rows flagged zero -- a x 0 adds exactly 0 -- and consults the flags only
+ * while they cover less than 4/5 of the rows (decided on the device, no host read).  in_flags with in_count == NULL:
+ * the flags are ALWAYS consulted, so rows flagged zero may hold anything (an operand written on a row subset only).
  *   rownorm_bwd_flags   : tagrec_rownorm_bwd_f32 + flags / count of its output rows (the head of the chain)
  *   spmm_normbwd_sparse : tagrec_spmm_normbwd_drop_f32 reading in_flags (may be NULL) and writing out_flags / out_count
  *                         (may be NULL).  row_mask (may be NULL): rows whose byte is 0 are left alone -- for a caller
  *                         who knows their result is zero (no flagged neighbour, and X_raw / inv_norm / dZ zero there, as
  *                         after the row-restricted forward) and has zeroed those rows of G_out / out_flags itself
- *   spmm_axpy_sparse    : tagrec_spmm_axpy_f32 reading in_flags */
+ *   spmm_axpy_sparse    : tagrec_spmm_axpy_f32 reading in_flags (may be NULL)
+ * dz_flags / b_flags (may be NULL): dz_flags[r] == 0 promises that row r of dZ (of B) is zero; the row's epilogue term
+ * then vanishes and neither dZ nor X_raw is read for it.  The gradient of a BPR batch w.r.t. the layer mean is non-zero
+ * on the <= 3 B batch rows only, so every backward layer skips 2 N D floats of epilogue reads.
+ * A product given in_flags walks a row's entries 64 at a time, keeps the entries whose operand row is flagged (order
+ * preserved) and gathers those alone. */
 int tagrec_rownorm_bwd_flags_f32(const float* X_raw, const float* inv_norm, const float* dZ, int64_t lddz,
                                  float d_scale, float* dX, int accumulate, int64_t n_rows, int D,
                                  uint8_t* row_flags, unsigned* count, void* stream);
 int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                    const unsigned* in_count, const float* X_raw, const float* inv_norm,
                                    const float* dZ, float d_scale, float drop_p, uint64_t seed, float* G_out,
-                                   uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask, int D, void* stream);
-int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                   uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask,
+                                   const uint8_t* dz_flags, int D, void* stream);
+int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags /* may be NULL */,
                                 const unsigned* in_count, const float* B, float b_scale, float* G_out,
-                                const uint8_t* row_mask /* may be NULL; as in spmm_normbwd_sparse */, int D, void* stream);
+                                const uint8_t* row_mask /* may be NULL; as in spmm_normbwd_sparse */,
+                                const uint8_t* b_flags, int D, void* stream);
 /* Forward layer on a SUBSET of the output rows.  The loss reads the propagated table at the batch rows only
  * (model/lightgcn.py:71-75), so the last layer is needed on those rows and the layer below it on their neighbours.
  *   graph_mark_rows   : flags[c] = 1 for every column index stored in the listed rows and for the rows themselves
  *                       (flags uint8 [n_rows], zeroed / pre-marked by the caller; square adjacency)
- *   spmm_norm_acc_rows: tagrec_spmm_norm_acc_drop_f32 for the rows with row_mask[r] != 0; the other rows of Y_raw,
- *                       inv_norm and acc are left untouched */
+ *   spmm_norm_acc_rows: tagrec_spmm_norm_acc_drop_f32 for the rows with row_mask[r] != 0 (NULL = every row); the other
+ *                       rows of Y_raw, inv_norm and acc are left untouched.  acc may be NULL: the layer mean is then
+ *                       not accumulated (a caller that reads it at a few rows forms it there from Y_raw and inv_norm) */
 int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, uint8_t* flags, void* stream);
 /* the same for a rectangular matrix: flags (uint8 [n_cols]) of the columns stored in the listed rows, rows not marked */
 int tagrec_graph_mark_cols_u8(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, uint8_t* flags, void* stream);

@@ -10,7 +10,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtagrec_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 LOSS_SOFTPLUS = 0
 LOSS_LOGSIGMOID = 1
@@ -89,8 +89,9 @@ _SIGNATURES = {
     "tagrec_rownorm_bwd_flags_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int, c_int64, c_int, c_void_p,
                                      c_void_p, c_void_p],
     "tagrec_spmm_normbwd_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
-                                       ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
-    "tagrec_spmm_axpy_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
+                                       ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_spmm_axpy_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p],
     "tagrec_spmm_normbwd_dot_sparse_f32": [c_void_p] * 8 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_graph_mark_rows_u8": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_graph_mark_cols_u8": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p],

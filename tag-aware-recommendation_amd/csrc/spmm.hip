@@ -50,6 +50,10 @@ struct EpiArgs {
   // written nor accumulated.  nullptr = every row.  The last forward layer is needed on the batch rows only and the one
   // before it on their neighbours (lightgcn.py: the loss reads `out` at the batch rows).
   const uint8_t* row_mask;
+  // NORMBWD / AXPY: b_flags[r] == 0 promises that row r of B (dZ) is zero, so the row's epilogue term vanishes and
+  // neither B nor X_raw is read for it (the BPR gradient w.r.t. the layer mean lives on the <= 3 B batch rows).
+  // nullptr = read every row.
+  const uint8_t* b_flags;
 };
 
 // Streamed-once data (indices, values, epilogue operands, outputs) is moved with non-temporal accesses so it does
@@ -86,13 +90,28 @@ __device__ __forceinline__ float4 gather_rows(const GraphView& g, const float* _
   const float4* __restrict__ Xv = reinterpret_cast<const float4*>(X) + (lane % LPR);
   float4 acc = f4_zero();
   for (int64_t base = start; base < end; base += kWave) {
-    const int n = (end - base) < kWave ? static_cast<int>(end - base) : kWave;
+    int n = (end - base) < kWave ? static_cast<int>(end - base) : kWave;
     int my_col = 0;
     float my_val = 0.f;
     if (lane < n) {
       my_col = ld_stream(g.col + base + lane);
       my_val = ld_stream(g.val + base + lane);
       if constexpr (FLAGS) my_val = flags[my_col] ? my_val : 0.f;      // a zero weight marks "row not needed"
+    }
+    if constexpr (FLAGS) {
+      // Keep only the entries whose operand row is flagged: they move to the first lanes (order preserved) and the
+      // gather loop below runs over them alone -- a batch of 64 entries with nothing flagged costs its index / flag reads
+      // and nothing else.  (dest is a permutation of the 64 lanes: flagged entries first, the rest behind them.)
+      const unsigned long long m = __ballot(my_val != 0.f);
+      const int cnt = __popcll(m);
+      if (cnt == 0) continue;
+      if (cnt < n) {
+        const int before = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
+        const int dest = (my_val != 0.f) ? before : cnt + (lane - before);
+        my_col = __builtin_amdgcn_ds_permute(dest << 2, my_col);
+        my_val = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(my_val)));
+        n = cnt;
+      }
     }
     const int groups = (n + NPI - 1) / NPI;
     for (int gi = 0; gi < groups; gi += 4) {
@@ -150,20 +169,25 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
     const float den = fmaxf(sqrtf(ss), 1e-12f);
     if (writer) {
       st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
-      float4 a = ld_stream(reinterpret_cast<const float4*>(e.accum) + off);
-      a.x = fmaf(e.s, acc.x / den, a.x);
-      a.y = fmaf(e.s, acc.y / den, a.y);
-      a.z = fmaf(e.s, acc.z / den, a.z);
-      a.w = fmaf(e.s, acc.w / den, a.w);
-      st_stream(reinterpret_cast<float4*>(e.accum) + off, a);
+      if (e.accum) {                      // nullptr: the caller forms the layer mean itself, on the rows it needs
+        float4 a = ld_stream(reinterpret_cast<const float4*>(e.accum) + off);
+        a.x = fmaf(e.s, acc.x / den, a.x);
+        a.y = fmaf(e.s, acc.y / den, a.y);
+        a.z = fmaf(e.s, acc.z / den, a.z);
+        a.w = fmaf(e.s, acc.w / den, a.w);
+        st_stream(reinterpret_cast<float4*>(e.accum) + off, a);
+      }
     }
     if (lane == 0) e.inv_norm[r] = 1.0f / den;
   } else if constexpr (EPI == EPI_NORMBWD) {
-    const float4 xr = ld_stream(reinterpret_cast<const float4*>(e.Xraw) + off);
-    float4 dz = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
-    dz.x *= e.s; dz.y *= e.s; dz.z *= e.s; dz.w *= e.s;
-    const float4 gz = normalize_bwd<LPR>(xr, e.inv_norm[r], dz);
-    float4 o = make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w);
+    float4 o = acc;
+    if (!e.b_flags || e.b_flags[r]) {     // (r is the same for every lane of the wave)
+      const float4 xr = ld_stream(reinterpret_cast<const float4*>(e.Xraw) + off);
+      float4 dz = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
+      dz.x *= e.s; dz.y *= e.s; dz.z *= e.s; dz.w *= e.s;
+      const float4 gz = normalize_bwd<LPR>(xr, e.inv_norm[r], dz);
+      o = make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w);
+    }
     drop4(e.drop, off, o.x, o.y, o.z, o.w);
     if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, o);
     if (e.out_flags) {
@@ -171,10 +195,14 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
       if (lane == 0) e.out_flags[r] = nz != 0.f;
     }
   } else if constexpr (EPI == EPI_AXPY) {
-    const float4 b = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
-    if (writer)
-      st_stream(reinterpret_cast<float4*>(e.Y) + off, make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y),
-                                                        fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w)));
+    if (e.b_flags && !e.b_flags[r]) {
+      if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
+    } else {
+      const float4 b = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
+      if (writer)
+        st_stream(reinterpret_cast<float4*>(e.Y) + off, make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y),
+                                                          fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w)));
+    }
   } else if constexpr (EPI == EPI_SS) {
     // column-sharded tables: the row norm needs every shard's columns, so only the local sum of squares is formed
     const float ss = group_sum<LPR>(f4_dot(acc, acc));
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
     const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
-    const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_cols);
+    const bool sparse = e.in_flags && (!e.in_count || 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_cols));
     const float4 acc = sparse ? gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags) : gather_rows<LPR>(g, X, start, end, lane);
     if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[c * LPR + lane] = acc;
     return;
@@ -223,7 +251,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
   if (MASKED && !e.row_mask[r]) return;
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
   if (end - start > kLongRow) return;  // chunked above, folded by spmm_finish_kernel
-  const bool sparse = e.in_flags && 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_cols);
+  const bool sparse = e.in_flags && (!e.in_count || 5ull * (*e.in_count) < 4ull * static_cast<unsigned long long>(g.n_cols));
   const float4 acc = sparse ? gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags) : gather_rows<LPR>(g, X, start, end, lane);
   row_epilogue<LPR, EPI>(acc, r, lane, e);
 }
@@ -590,7 +618,9 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
       default: break;
     }
   }
-  if (e.row_mask || e.in_flags || e.out_flags)
+  if (EPI == EPI_NORM_ACC && !e.accum)
+    return fail(TAGREC_E_INVALID, std::string(who) + ": acc may be NULL only with the vector kernels (D in {8,...,256}, aligned rows)");
+  if (e.row_mask || e.in_flags || e.out_flags || e.b_flags)
     return fail(TAGREC_E_INVALID, std::string(who) + ": row masks / row flags need the vector kernels (D in {8,...,256}, "
                                                      "every operand 16-byte aligned); the scalar kernel would ignore them");
   if (D > kMaxGenericBlocks * kWave)
@@ -671,14 +701,14 @@ extern "C" int tagrec_spmm_normbwd_drop_f32(const tagrec_graph* g, const float* 
 extern "C" int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                               const unsigned* in_count, const float* X_raw, const float* inv_norm,
                                               const float* dZ, float d_scale, float drop_p, uint64_t seed, float* G_out,
-                                              uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask, int D,
-                                              void* stream) {
+                                              uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask,
+                                              const uint8_t* dz_flags, int D, void* stream) {
   TAGREC_REQUIRE(X_raw != nullptr && inv_norm != nullptr && dZ != nullptr, "spmm_normbwd_sparse: null X_raw, inv_norm or dZ");
-  TAGREC_REQUIRE((in_flags == nullptr) == (in_count == nullptr), "spmm_normbwd_sparse: in_flags and in_count go together");
+  TAGREC_REQUIRE(in_flags != nullptr || in_count == nullptr, "spmm_normbwd_sparse: in_count without in_flags");
   TAGREC_REQUIRE((out_flags == nullptr) == (out_count == nullptr), "spmm_normbwd_sparse: out_flags and out_count go together");
   TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_normbwd_sparse: p must be in [0, 1)");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_normbwd_sparse: D must be 8 .. 256, a power of two");
-  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}, in_flags, in_count, out_flags, row_mask};
+  EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, nullptr, d_scale, DropMask{drop_p, seed}, in_flags, in_count, out_flags, row_mask, dz_flags};
   int rc = launch_spmm<EPI_NORMBWD>(g, G_in, e, D, stream, "spmm_normbwd_sparse");
   if (rc != TAGREC_OK || !out_flags) return rc;
   return count_flags(out_flags, g->n_rows, out_count, static_cast<hipStream_t>(stream));
@@ -686,10 +716,11 @@ extern "C" int tagrec_spmm_normbwd_sparse_f32(const tagrec_graph* g, const float
 
 extern "C" int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                            const unsigned* in_count, const float* B, float b_scale, float* G_out,
-                                           const uint8_t* row_mask, int D, void* stream) {
-  TAGREC_REQUIRE(B != nullptr && in_flags != nullptr && in_count != nullptr, "spmm_axpy_sparse: null B, in_flags or in_count");
+                                           const uint8_t* row_mask, const uint8_t* b_flags, int D, void* stream) {
+  TAGREC_REQUIRE(B != nullptr, "spmm_axpy_sparse: null B");
+  TAGREC_REQUIRE(in_flags != nullptr || in_count == nullptr, "spmm_axpy_sparse: in_count without in_flags");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_sparse: D must be 8 .. 256, a power of two");
-  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, row_mask};
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, row_mask, b_flags};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_sparse");
 }
 
@@ -759,10 +790,10 @@ extern "C" int tagrec_spmm_listed_f32(const tagrec_graph* g, const int64_t* rows
 extern "C" int tagrec_spmm_norm_acc_rows_f32(const tagrec_graph* g, const float* X, float* Y_raw, float* inv_norm,
                                              float* acc, float acc_scale, const uint8_t* row_mask, float drop_p,
                                              uint64_t seed, int D, void* stream) {
-  TAGREC_REQUIRE(inv_norm != nullptr && acc != nullptr && row_mask != nullptr, "spmm_norm_acc_rows: null inv_norm, acc or row_mask");
+  TAGREC_REQUIRE(inv_norm != nullptr, "spmm_norm_acc_rows: null inv_norm");
   TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "spmm_norm_acc_rows: p must be in [0, 1)");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_norm_acc_rows: D must be 8 .. 256, a power of two");
-  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr, row_mask};
+  EpiArgs e{Y_raw, inv_norm, acc, nullptr, nullptr, nullptr, acc_scale, DropMask{drop_p, seed}, nullptr, nullptr, nullptr, row_mask, nullptr};
   return launch_spmm<EPI_NORM_ACC>(g, X, e, D, stream, "spmm_norm_acc_rows");
 }
 

@@ -336,9 +336,11 @@ class Graph:
         return out
 
     def spmm_norm_acc_rows(self, X, y_raw, inv_norm, acc, acc_scale, row_mask, drop_p=0.0, seed=0):
-        """`spmm_norm_acc` for the rows with row_mask[r] != 0 only (the others are left as they are)."""
+        """`spmm_norm_acc` for the rows with row_mask[r] != 0 only (the others are left as they are; None = every row).
+        acc None: the layer mean is not accumulated."""
         D = self._chk_x(X, self.shape[1], "spmm_norm_acc X")
-        self._call("spmm_norm_acc_rows", _lib.load().tagrec_spmm_norm_acc_rows_f32, self._h, _lib.ptr(X), _lib.ptr(y_raw),
+        self._call("spmm_norm_acc_rows" if row_mask is not None else "spmm_norm_acc", _lib.load().tagrec_spmm_norm_acc_rows_f32,
+                   self._h, _lib.ptr(X), _lib.ptr(y_raw),
                    _lib.ptr(inv_norm), _lib.ptr(acc), float(acc_scale), _lib.ptr(row_mask), float(drop_p), int(seed), D,
                    _lib.stream_ptr())
 
@@ -356,7 +358,7 @@ class Graph:
                    _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), _lib.ptr(g_out), D, _lib.stream_ptr())
 
     def spmm_normbwd_sparse(self, g_in, in_flags, in_count, x_raw, inv_norm, dz, d_scale, g_out, out_flags, out_count,
-                            drop_p=0.0, seed=0, row_mask=None):
+                            drop_p=0.0, seed=0, row_mask=None, dz_flags=None):
         """`spmm_normbwd` on a row-sparse g_in: rows whose in_flags byte is 0 are not gathered (same result); writes the
         flags / count of its own output when out_flags is given.  row_mask: rows whose byte is 0 are not touched at all
         (the caller knows their result is zero and has zeroed g_out / out_flags there)."""
@@ -368,11 +370,12 @@ class Graph:
         self._call("spmm_normbwd_rows" if row_mask is not None else "spmm_normbwd", _lib.load().tagrec_spmm_normbwd_sparse_f32,
                    self._h, _lib.ptr(g_in), _lib.ptr(in_flags),
                    _lib.ptr(in_count), _lib.ptr(x_raw), _lib.ptr(inv_norm), _lib.ptr(dz), float(d_scale), float(drop_p),
-                   int(seed), _lib.ptr(g_out), _lib.ptr(out_flags), _lib.ptr(out_count), _lib.ptr(row_mask), D,
+                   int(seed), _lib.ptr(g_out), _lib.ptr(out_flags), _lib.ptr(out_count), _lib.ptr(row_mask), _lib.ptr(dz_flags), D,
                    _lib.stream_ptr())
 
-    def spmm_axpy_sparse(self, g_in, in_flags, in_count, b, b_scale, g_out, row_mask=None):
-        """row_mask: rows whose byte is 0 are not touched (the caller knows their result and has written it)."""
+    def spmm_axpy_sparse(self, g_in, in_flags, in_count, b, b_scale, g_out, row_mask=None, b_flags=None):
+        """row_mask: rows whose byte is 0 are not touched (the caller knows their result and has written it).
+        b_flags: rows of `b` whose byte is 0 are zero and are not read."""
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")
         if row_mask is not None:
             _lib.require_gpu_tensor(row_mask, torch.uint8, "row_mask")
@@ -380,7 +383,7 @@ class Graph:
                 raise _lib.TagrecError("spmm_axpy_sparse: row_mask must have one byte per row")
         self._call("spmm_axpy_rows" if row_mask is not None else "spmm_axpy", _lib.load().tagrec_spmm_axpy_sparse_f32, self._h,
                    _lib.ptr(g_in), _lib.ptr(in_flags), _lib.ptr(in_count), _lib.ptr(b), float(b_scale), _lib.ptr(g_out),
-                   _lib.ptr(row_mask), D, _lib.stream_ptr())
+                   _lib.ptr(row_mask), _lib.ptr(b_flags), D, _lib.stream_ptr())
 
     def spmm_axpy(self, g_in, b, b_scale, g_out):
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")

@@ -117,6 +117,88 @@ def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0, masks=Non
     return g0
 
 
+VEC_WIDTHS = (8, 16, 32, 64, 128, 256)
+
+
+def spmm_listed(graph, rows, x):
+    """(A x)[rows] as a compact [len(rows), D] tensor (rows int64, may repeat)."""
+    rows = rows.contiguous()
+    out = torch.empty(rows.numel(), x.shape[1], dtype=torch.float32, device=x.device)
+    graph._call("spmm_listed", _lib.load().tagrec_spmm_listed_f32, graph.handle, _lib.ptr(rows), rows.numel(), _lib.ptr(x),
+                _lib.ptr(out), x.shape[1], _lib.stream_ptr())
+    return out
+
+
+def restricted_forward(graph, x0, n_layer, rows):
+    """The forward pass of a training step whose loss reads the layer mean at `rows` (int64 node ids [T], may repeat)
+    only -- the BPR batch rows (lightgcn.py:71-75).  Layers below L-1 run on all rows (through the popular items every
+    row is within two hops of the batch), layer L-1 on the batch rows and their neighbours (row-masked kernel), layer L
+    in compact form on the batch rows alone (`spmm_listed`); no layer accumulates the mean, which is formed at the end
+    on the T rows.  Returns (out_b [T, D], state for `restricted_backward`).  Rows a layer did not compute are left
+    UNWRITTEN in its output; every later reader is told which rows are valid."""
+    L, s = n_layer, 1.0 / (n_layer + 1)
+    n, D = x0.shape
+    T = rows.numel()
+    mid = graph.mark_rows(rows, torch.zeros(n, dtype=torch.uint8, device=x0.device)) if L >= 2 else None
+    raws, invs = [], []
+    x = x0
+    for k in range(L - 1):
+        y = torch.empty_like(x0)
+        inv = torch.empty(n, dtype=torch.float32, device=x0.device)
+        graph.spmm_norm_acc_rows(x, y, inv, None, 0.0, mid if k == L - 2 else None)
+        raws.append(y)
+        invs.append(inv)
+        x = y
+    y_top = spmm_listed(graph, rows, x)
+    z_top = torch.empty_like(y_top)
+    inv_top = torch.empty(T, dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.load().tagrec_rownorm_fwd_f32(_lib.ptr(y_top), _lib.ptr(z_top), D, _lib.ptr(inv_top), T, D, _lib.stream_ptr()),
+               "rownorm_fwd")
+    out_b = x0.index_select(0, rows) * s
+    for y, inv in zip(raws, invs):
+        out_b.addcmul_(y.index_select(0, rows), inv.index_select(0, rows)[:, None], value=s)
+    out_b.add_(z_top, alpha=s)
+    return out_b, (raws, invs, mid, y_top, inv_top)
+
+
+def restricted_backward(graph_t, rows, d_out_b, state, shape):
+    """Gradient w.r.t. x0 of `restricted_forward` given d_out_b [T, D] = d loss / d out_b.  The chain starts on the batch
+    rows (compact), lands on their neighbours (row-masked hop: G is non-zero there only) and spreads from there; every
+    operand travels with one flag byte per row and zero rows are not gathered; the normalize-backward / mean terms exist
+    on the batch rows only (dz_flags), so no other row's epilogue reads X_raw or dZ."""
+    raws, invs, mid, y_top, inv_top = state
+    n, D = shape
+    L = len(raws) + 1
+    s = 1.0 / (L + 1)
+    T = rows.numel()
+    dev = d_out_b.device
+    lib = _lib.load()
+    tflag = torch.zeros(n, dtype=torch.uint8, device=dev)
+    tflag.index_fill_(0, rows, 1)
+    dz = torch.empty(n, D, dtype=torch.float32, device=dev)             # d loss / d out, valid on the batch rows only
+    dz.index_fill_(0, rows, 0.0)
+    dz.index_add_(0, rows, d_out_b)
+    g_top = torch.empty(T, D, dtype=torch.float32, device=dev)
+    _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(y_top), _lib.ptr(inv_top), _lib.ptr(d_out_b), D, s, _lib.ptr(g_top), 0, T, D,
+                                          _lib.stream_ptr()), "rownorm_bwd")
+    g = torch.empty(n, D, dtype=torch.float32, device=dev)               # G^L: valid on the batch rows only (flags = tflag)
+    g.index_fill_(0, rows, 0.0)
+    g.index_add_(0, rows, g_top)
+    flags, count = tflag, None                                           # count None: the flags are always consulted
+    for k in range(L - 2, -1, -1):
+        masked = k == L - 2
+        gn = torch.empty(n, D, dtype=torch.float32, device=dev)
+        fo = (torch.zeros if masked else torch.empty)(n, dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        graph_t.spmm_normbwd_sparse(g, flags, count, raws[k], invs[k], dz, s, gn, fo, cnt, row_mask=mid if masked else None,
+                                    dz_flags=tflag)
+        # a masked hop wrote the rows of `mid` only: its flags must always be honoured; a full hop wrote every row
+        g, flags, count = gn, fo, (None if masked else cnt)
+    g0 = torch.empty(n, D, dtype=torch.float32, device=dev)
+    graph_t.spmm_axpy_sparse(g, flags, count, dz, s, g0, b_flags=tflag)
+    return g0
+
+
 class _Propagate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, graph, n_layer, drops=None, seed=0):
@@ -137,34 +219,63 @@ class _PropagateBprLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active, drops=None, seed=0, restrict=True):
         x0 = table.detach()
-        loss_rows = None
-        if restrict:                     # the loss reads `out` at the batch rows only: users, and items offset by n_user
-            loss_rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user])
-        ctx.masks = {}
-        out, raws, invs = propagate_forward(graph, x0, n_layer, drops, seed, loss_rows, ctx.masks)
-        ctx.drops, ctx.seed = drops, seed
         B, D = trip.shape[0], x0.shape[1]
+        n = x0.shape[0]
+        lib = _lib.load()
         coef = torch.empty(B, dtype=torch.float32, device=x0.device)
         partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=x0.device)
         res = torch.empty(2, dtype=torch.float32, device=x0.device)
+        ctx.n_user, ctx.n_item, ctx.reg_active, ctx.trip, ctx.coef, ctx.graph = n_user, n_item, reg_active, trip, coef, graph
+        # the loss reads `out` at the batch rows only: users, and items offset by n_user
+        rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user]) if restrict else None
+        ctx.compact = bool(restrict and drops is None and n_layer >= 1 and graph.shape[0] == graph.shape[1] and D in VEC_WIDTHS
+                           and 3 * B * 16 <= n)                       # a batch that touches most rows gains nothing
+        if ctx.compact:
+            out_b, ctx.state = restricted_forward(graph, x0, n_layer, rows)
+            ego_b = x0.index_select(0, rows)
+            ar = torch.arange(B, device=x0.device)
+            ctrip = torch.stack([ar, ar, ar + B], dim=1).contiguous()
+            _lib.check(lib.tagrec_bpr_fwd_f32(_lib.ptr(out_b[:B]), _lib.ptr(out_b[B:]), D, D, _lib.ptr(ego_b[:B]), _lib.ptr(ego_b[B:]),
+                                              D, D, _lib.ptr(ctrip), B, loss_kind, _lib.ptr(coef), _lib.ptr(partials),
+                                              _lib.ptr(res), _lib.stream_ptr()), "bpr_fwd")
+            ctx.rows, ctx.out_b, ctx.ego_b, ctx.ctrip, ctx.shape = rows, out_b, ego_b, ctrip, x0.shape
+            return res
+        ctx.masks = {}
+        out, raws, invs = propagate_forward(graph, x0, n_layer, drops, seed, rows, ctx.masks)
+        ctx.drops, ctx.seed = drops, seed
         U, I = out[:n_user], out[n_user:n_user + n_item]
         Ue, Ie = x0[:n_user], x0[n_user:n_user + n_item]
-        _lib.check(_lib.load().tagrec_bpr_fwd_f32(_lib.ptr(U), _lib.ptr(I), D, D, _lib.ptr(Ue), _lib.ptr(Ie), D, D,
-                                                  _lib.ptr(trip), B, loss_kind, _lib.ptr(coef), _lib.ptr(partials),
-                                                  _lib.ptr(res), _lib.stream_ptr()), "bpr_fwd")
-        ctx.graph, ctx.raws, ctx.invs = graph, raws, invs
-        ctx.out, ctx.x0, ctx.trip, ctx.coef = out, x0, trip, coef
-        ctx.n_user, ctx.n_item, ctx.reg_active = n_user, n_item, reg_active
+        _lib.check(lib.tagrec_bpr_fwd_f32(_lib.ptr(U), _lib.ptr(I), D, D, _lib.ptr(Ue), _lib.ptr(Ie), D, D,
+                                          _lib.ptr(trip), B, loss_kind, _lib.ptr(coef), _lib.ptr(partials),
+                                          _lib.ptr(res), _lib.stream_ptr()), "bpr_fwd")
+        ctx.raws, ctx.invs = raws, invs
+        ctx.out, ctx.x0 = out, x0
         return res
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
+        lib = _lib.load()
+        null = _lib.c_void_p(0)
+        if ctx.compact:
+            out_b, ego_b, ctrip, rows = ctx.out_b, ctx.ego_b, ctx.ctrip, ctx.rows
+            B, D = ctrip.shape[0], out_b.shape[1]
+            d_b = torch.zeros(2, 3 * B, D, dtype=torch.float32, device=out_b.device)   # d / d out_b, d / d ego_b
+            reg = ctx.reg_active
+            _lib.check(lib.tagrec_bpr_bwd_f32(_lib.ptr(out_b[:B]), _lib.ptr(out_b[B:]), D, D,
+                                              _lib.ptr(ego_b[:B]) if reg else null, _lib.ptr(ego_b[B:]) if reg else null,
+                                              D if reg else 0, D if reg else 0, _lib.ptr(ctrip), B, _lib.ptr(ctx.coef), _lib.ptr(g), 1.0,
+                                              _lib.ptr(d_b[0][:B]), _lib.ptr(d_b[0][B:]),
+                                              _lib.ptr(d_b[1][:B]) if reg else null, _lib.ptr(d_b[1][B:]) if reg else null,
+                                              _lib.stream_ptr()), "bpr_bwd")
+            g0 = restricted_backward(ctx.graph.transpose(), rows, d_b[0], ctx.state, ctx.shape)
+            if ctx.reg_active:
+                g0.index_add_(0, rows, d_b[1])                            # L2 term on the ego rows
+            ctx.state = ctx.out_b = None
+            return g0, None, None, None, None, None, None, None, None, None, None
         out, x0, trip = ctx.out, ctx.x0, ctx.trip
         nu, ni, D, B = ctx.n_user, ctx.n_item, x0.shape[1], trip.shape[0]
-        lib = _lib.load()
         d_out = torch.zeros_like(out)
-        null = _lib.c_void_p(0)
         U, I = out[:nu], out[nu:nu + ni]
         _lib.check(lib.tagrec_bpr_bwd_f32(_lib.ptr(U), _lib.ptr(I), D, D, null, null, 0, 0, _lib.ptr(trip), B,
                                           _lib.ptr(ctx.coef), _lib.ptr(g), 1.0,

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/tagrec.h but not exported"
     assert sorted(T._lib.exported_symbols()) == declared, "ctypes table and header disagree"
-    assert lib.tagrec_abi_version() == 1
+    assert lib.tagrec_abi_version() == 2
 
 
 def test_missing_gpu_fails_loudly():

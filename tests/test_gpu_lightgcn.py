@@ -403,9 +403,11 @@ def test_restricted_forward_equals_full_forward_step(n_layer):
         sum(lossx).backward()
         res.append(([float(v) for v in lossx], m.table.grad.clone()))
     (l0, g0), (l1, g1) = res
-    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)
     scale = float(g0.abs().max())
-    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-4, atol=1e-6 * scale)
+    # the restricted step sums in another order (top layer: four waves per batch row; flagged entries of a row are packed
+    # before they are gathered), so entries that cancel to ~1e-6 of the largest gradient differ in their last digits
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-3, atol=1e-5 * scale)
 
 
 def test_feature_sharded_restricted_step_equals_single_gpu_model():
