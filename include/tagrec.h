@@ -151,11 +151,14 @@ int tagrec_spmm_ss_rows_f32(const tagrec_graph* g, const float* X, float* Y, flo
                             void* stream);
 /* The plain product on a short LIST of rows with a compact result: Y[k, :] = (A @ X)[rows[k], :], k < n_listed
  * (rows int64, may repeat; rows[k] is NOT range-checked on the device -- the caller guarantees 0 <= rows[k] < n_rows).
- * One block per listed row, fixed summation order.  With A = the column slice A[:, rows_g] of a row-sharded table
- * this is rank g's share of the top layer at the batch rows (the 1-D fold partition of adj.py:114-140,158-164 turned
- * into push form where the output is 3 B rows); the shares are summed by an all-reduce of [3 B, D]. */
+ * Every listed row is cut into 32 ranges summed by separate blocks (batch rows are popular items: 1e5 entries), partial
+ * rows go to `ws` (tagrec_spmm_listed_workspace(n_listed, D) floats, caller-provided) and are added in a fixed order.
+ * This is the top layer of a training step -- the loss reads it at the <= 3 B batch rows (model/lightgcn.py:71-75) -- and,
+ * with A = the column slice A[:, rows_g] of a row-sharded table, rank g's share of it (the 1-D fold partition of
+ * adj.py:114-140,158-164 in push form where the output is 3 B rows); the shares are summed by an all-reduce of [3 B, D]. */
+int64_t tagrec_spmm_listed_workspace(int64_t n_listed, int D);
 int tagrec_spmm_listed_f32(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, const float* X, float* Y,
-                           int D, void* stream);
+                           int D, float* ws, int64_t ws_floats, void* stream);
 /* tagrec_spmm_normbwd_dot_f32 (column-sharded tables) on a row-sparse G_in */
 int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
                                        const unsigned* in_count, const float* X_raw, const float* inv_norm,

@@ -95,8 +95,11 @@ __device__ __forceinline__ float4 gather_rows(const GraphView& g, const float* _
     float my_val = 0.f;
     if (lane < n) {
       my_col = ld_stream(g.col + base + lane);
-      my_val = ld_stream(g.val + base + lane);
-      if constexpr (FLAGS) my_val = flags[my_col] ? my_val : 0.f;      // a zero weight marks "row not needed"
+      if constexpr (FLAGS) {
+        if (flags[my_col]) my_val = ld_stream(g.val + base + lane);    // a zero weight marks "row not needed"
+      } else {
+        my_val = ld_stream(g.val + base + lane);
+      }
     }
     if constexpr (FLAGS) {
       // Keep only the entries whose operand row is flagged: they move to the first lanes (order preserved) and the
@@ -387,21 +390,34 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_generic_kern
 
 
 // ---- product on a short LIST of rows, compact output: Y[k, :] = sum_j val_j X[col_j, :] over row rows[k] ----------
-// One block per listed row; its four waves take contiguous quarters of the row (multiples of 64 entries) and the
-// partial sums are folded in wave order through LDS, so the result is reproducible.  This is the top layer of the
-// row-sharded step (dist.py): the loss reads that layer at the <= 3 B batch rows only, and each rank adds the part of
-// those rows' neighbourhoods it owns.
+// This is the top layer of a training step (the loss reads that layer at the <= 3 B batch rows only) and, with
+// A = the column slice A[:, rows_g], a rank's share of it in the row-sharded step (dist.py).  The listed rows are the
+// batch's users and items, and positive items are popular: rows of 1e5 entries are the common case.  So every listed row
+// is cut into kListedSplits equal ranges (multiples of 64 entries); block (k, s) sums range s of row k with its four
+// waves (each a contiguous quarter, folded in wave order through LDS) into ws[k][s], and a second kernel adds the
+// kListedSplits partial rows in order: a fixed summation order, and the longest row costs 1/128 of its length per wave.
+constexpr int kListedSplits = 32;
+
 template <int LPR>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_listed_kernel(GraphView g, const int64_t* __restrict__ rows,
-                                                                              const float* __restrict__ X, float* __restrict__ Y) {
+                                                                              const float* __restrict__ X, float* __restrict__ ws) {
   __shared__ float4 part[kWavesPerBlock][LPR];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int64_t k = blockIdx.x;
+  const int64_t k = blockIdx.x / kListedSplits;
+  const int sp = blockIdx.x % kListedSplits;
   const int64_t r = rows[k];
   const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
-  const int64_t per = ((end - start + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave)) * kWave;
-  const int64_t s0 = (start + wave * per < end) ? start + wave * per : end;
-  const int64_t s1 = (s0 + per < end) ? s0 + per : end;
+  const int64_t per_split = ((end - start + kListedSplits * kWave - 1) / (kListedSplits * kWave)) * kWave;
+  const int64_t b0 = (start + sp * per_split < end) ? start + sp * per_split : end;
+  const int64_t b1 = (b0 + per_split < end) ? b0 + per_split : end;
+  float4* out = reinterpret_cast<float4*>(ws) + (k * kListedSplits + sp) * LPR;
+  if (b0 >= b1) {                                   // nothing in this range (short rows use the first ranges only)
+    if (threadIdx.x < LPR) out[threadIdx.x] = f4_zero();
+    return;
+  }
+  const int64_t per = ((b1 - b0 + kWavesPerBlock * kWave - 1) / (kWavesPerBlock * kWave)) * kWave;
+  const int64_t s0 = (b0 + wave * per < b1) ? b0 + wave * per : b1;
+  const int64_t s1 = (s0 + per < b1) ? s0 + per : b1;
   const float4 acc = gather_rows<LPR>(g, X, s0, s1, lane);
   if (lane < LPR) part[wave][lane] = acc;
   __syncthreads();
@@ -412,8 +428,24 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_listed_kernel(Gra
       const float4 b = part[w][lane];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    reinterpret_cast<float4*>(Y)[k * LPR + lane] = a;
+    out[lane] = a;
   }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_listed_fold_kernel(const float* __restrict__ ws, float* __restrict__ Y, int64_t n_listed) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;      // one float4 of the output per thread
+  if (i >= n_listed * LPR) return;
+  const int64_t k = i / LPR;
+  const int c = static_cast<int>(i % LPR);
+  const float4* p = reinterpret_cast<const float4*>(ws) + k * kListedSplits * LPR + c;
+  float4 a = p[0];
+#pragma unroll 4
+  for (int sp = 1; sp < kListedSplits; ++sp) {
+    const float4 b = p[static_cast<int64_t>(sp) * LPR];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  reinterpret_cast<float4*>(Y)[i] = a;
 }
 
 // flags[c] = 1 for every column index stored in the listed rows, and for the rows themselves (block per listed row)
@@ -764,25 +796,37 @@ extern "C" int tagrec_graph_mark_cols_u8(const tagrec_graph* g, const int64_t* r
   return TAGREC_OK;
 }
 
+extern "C" int64_t tagrec_spmm_listed_workspace(int64_t n_listed, int D) {
+  return n_listed < 0 || D < 1 ? 0 : n_listed * kListedSplits * static_cast<int64_t>(D);
+}
+
 extern "C" int tagrec_spmm_listed_f32(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, const float* X, float* Y,
-                                      int D, void* stream) {
+                                      int D, float* ws, int64_t ws_floats, void* stream) {
   TAGREC_REQUIRE(g != nullptr && X != nullptr && Y != nullptr && (n_listed == 0 || rows != nullptr), "spmm_listed: null pointer");
-  TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "spmm_listed: bad row count");
-  TAGREC_REQUIRE(aligned16(X) && aligned16(Y), "spmm_listed: rows must be 16-byte aligned");
+  TAGREC_REQUIRE(n_listed >= 0 && n_listed * kListedSplits < (1ll << 31), "spmm_listed: bad row count");
+  TAGREC_REQUIRE(aligned16(X) && aligned16(Y) && aligned16(ws), "spmm_listed: rows must be 16-byte aligned");
+  TAGREC_REQUIRE(n_listed == 0 || (ws != nullptr && ws_floats >= tagrec_spmm_listed_workspace(n_listed, D)),
+                 "spmm_listed: workspace smaller than tagrec_spmm_listed_workspace(n_listed, D)");
   if (n_listed == 0) return TAGREC_OK;
   const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned blocks = static_cast<unsigned>(n_listed);
+  const unsigned blocks = static_cast<unsigned>(n_listed * kListedSplits);
   const int threads = kWavesPerBlock * kWave;
+#define LISTED(L)                                                                                   \
+  spmm_listed_kernel<L><<<blocks, threads, 0, s>>>(gv, rows, X, ws);                                \
+  TAGREC_LAUNCH_CHECK();                                                                            \
+  spmm_listed_fold_kernel<L><<<static_cast<unsigned>((n_listed * L + 255) / 256), 256, 0, s>>>(ws, Y, n_listed); \
+  break
   switch (D) {
-    case 8: spmm_listed_kernel<2><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
-    case 16: spmm_listed_kernel<4><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
-    case 32: spmm_listed_kernel<8><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
-    case 64: spmm_listed_kernel<16><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
-    case 128: spmm_listed_kernel<32><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
-    case 256: spmm_listed_kernel<64><<<blocks, threads, 0, s>>>(gv, rows, X, Y); break;
+    case 8: LISTED(2);
+    case 16: LISTED(4);
+    case 32: LISTED(8);
+    case 64: LISTED(16);
+    case 128: LISTED(32);
+    case 256: LISTED(64);
     default: return fail(TAGREC_E_UNSUPPORTED, "spmm_listed: D must be 8 .. 256, a power of two");
   }
+#undef LISTED
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

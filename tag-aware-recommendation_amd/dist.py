@@ -56,28 +56,31 @@ class HipOps:
                                                          _lib.stream_ptr()), "graph_mark_cols")
 
     def spmm_listed(self, g, rows, x, out):
-        rows = rows.contiguous()
-        g._call("spmm_listed", _lib.load().tagrec_spmm_listed_f32, g.handle, _lib.ptr(rows), rows.numel(), _lib.ptr(x),
-                _lib.ptr(out), x.shape[1], _lib.stream_ptr())
+        from .lightgcn import spmm_listed
+        spmm_listed(g, rows, x, out)
 
     def layer_fwd(self, g, x_full, y, inv, acc, s, row_mask=None):
-        if row_mask is None:
+        """acc None: the layer mean is not accumulated.  row_mask: only these rows are computed / written."""
+        if row_mask is None and acc is not None:
             g.spmm_norm_acc(x_full, y, inv, acc, s)
         else:
             g.spmm_norm_acc_rows(x_full, y, inv, acc, s, row_mask)
 
-    def layer_bwd(self, g, g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, row_mask=None):
-        if in_flags is None and out_flags is None and row_mask is None:
+    def layer_bwd(self, g, g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, row_mask=None, dz_flags=None):
+        """in_flags with in_count None: rows flagged zero may hold anything and are never read.  dz_flags: rows of dz whose
+        byte is 0 are zero (and may be unwritten)."""
+        if in_flags is None and out_flags is None and row_mask is None and dz_flags is None:
             g.spmm_normbwd(g_in, x_raw, inv, dz, s, out)
             return
         cnt = torch.empty(1, dtype=torch.int32, device=out.device) if out_flags is not None else None
-        g.spmm_normbwd_sparse(g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, cnt, row_mask=row_mask)
+        g.spmm_normbwd_sparse(g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, cnt, row_mask=row_mask,
+                              dz_flags=dz_flags)
 
-    def last_hop(self, g, g_in, in_flags, in_count, b, s, out):
-        if in_flags is None:
+    def last_hop(self, g, g_in, in_flags, in_count, b, s, out, b_flags=None):
+        if in_flags is None and b_flags is None:
             g.spmm_axpy(g_in, b, s, out)
         else:
-            g.spmm_axpy_sparse(g_in, in_flags, in_count, b, s, out)
+            g.spmm_axpy_sparse(g_in, in_flags, in_count, b, s, out, b_flags=b_flags)
 
     def rownorm_fwd(self, x):
         n, D = x.shape
@@ -307,7 +310,6 @@ class _ShardedLoss(torch.autograd.Function):
         vec = D in (8, 16, 32, 64, 128, 256)
         restricted = bool(m.restrict_forward and getattr(ops, "restrict_forward", False) and L >= 1 and vec
                           and T * m.restrict_min_ratio <= part.n)
-        out = x0 * s
         raws, invs = [], []
         mid_mask = None
         if restricted and L >= 2:
@@ -324,24 +326,26 @@ class _ShardedLoss(torch.autograd.Function):
             xf = gat.table()
             feeds_pull = k + 1 < n_pull                    # its output is gathered for the next pull layer
             gat = _Gather(m, D, key=("fwd", k & 1)) if feeds_pull else None
-            if masked:
-                y = torch.zeros_like(x0)
-                inv = torch.zeros(part.per, dtype=torch.float32, device=dev)
-            else:
-                y = torch.empty_like(x0)
-                inv = torch.empty(part.per, dtype=torch.float32, device=dev)
+            # rows outside the mask are left unwritten: every later reader is confined to the mask
+            y = torch.empty_like(x0)
+            inv = torch.empty(part.per, dtype=torch.float32, device=dev)
             for c in range(part.n_chunks):
                 r = part.chunk_rows(c)
-                ops.layer_fwd(m.graph_chunks[c], xf, y[r], inv[r], out[r], s, mid_mask[r] if masked else None)
+                ops.layer_fwd(m.graph_chunks[c], xf, y[r], inv[r], None, s, mid_mask[r] if masked else None)
                 if feeds_pull:
                     gat.put(c, y[r])
             raws.append(y)
             invs.append(inv)
             x = y
-        # batch rows: every rank contributes what it owns to a [*, T, D] buffer, one all-reduce completes it
+        # batch rows: every rank contributes what it owns to a [*, T, D] buffer, one all-reduce completes it.  The layer
+        # mean is formed here, on the batch rows this rank owns (no layer accumulates it over the whole shard).
         buf = torch.zeros(3 if restricted else 2, T, D, dtype=torch.float32, device=dev)
-        buf[0][slot] = out[loc]
-        buf[1][slot] = x0[loc]
+        ego = x0.index_select(0, loc)
+        mean = ego * s
+        for y, inv in zip(raws, invs):
+            mean.addcmul_(y.index_select(0, loc), inv.index_select(0, loc)[:, None], value=s)
+        buf[0].index_copy_(0, slot, mean)
+        buf[1].index_copy_(0, slot, ego)
         if restricted:
             # top layer in push form: this rank's share of (A x)[batch rows] from the rows of x it owns
             ops.spmm_listed(m.graph_cols, rows_p, x, buf[2])
@@ -376,29 +380,35 @@ class _ShardedLoss(torch.autograd.Function):
         d_b = torch.zeros(2, T, D, dtype=torch.float32, device=dev)        # d loss / d out_b, d loss / d ego_b (replicated)
         ops.bpr_bwd(out_b[:B], out_b[B:], ego_b[:B], ego_b[B:], ctrip, ctx.coef, g.contiguous(),
                     d_b[0][:B], d_b[0][B:], d_b[1][:B], d_b[1][B:])
-        d_out = torch.zeros(ctx.shape, dtype=torch.float32, device=dev)    # gradient w.r.t. `out`, local rows
+        # gradient w.r.t. the layer mean on the local rows: non-zero on the batch rows this rank owns.  The restricted step
+        # tells every epilogue so (dz_flags) and leaves the other rows unwritten; the all-rows step zero-fills.
+        dzf = None
+        if restricted:
+            d_out = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
+            d_out.index_fill_(0, ctx.loc, 0.0)
+            dzf = torch.zeros(part.per, dtype=torch.uint8, device=dev)
+            dzf.index_fill_(0, ctx.loc, 1)
+        else:
+            d_out = torch.zeros(ctx.shape, dtype=torch.float32, device=dev)
         d_out.index_add_(0, ctx.loc, d_b[0][ctx.slot])
         n_pull = len(raws)
-        head_rows = None
-        # ---- head of the chain: G^L, either on the batch rows (restricted) or on the local rows
         if L == 0:
             g0 = d_out
         else:
+            # ---- head of the chain: G^L, either on the batch rows (restricted) or on the local rows
             if restricted:
+                if not sparse:
+                    raise _lib.TagrecError("restricted sharded step needs the row-flag kernels")
                 g_top = torch.empty(T, D, dtype=torch.float32, device=dev)
                 ops.rownorm_bwd(ctx.y_top, ctx.inv_top, d_b[0], s, g_top)
-                # the operand of the next product: zero except at the batch rows (slots naming one node are summed)
-                # (the buffer is all-zero between steps: a product that decides to ignore the row flags -- they cover
-                # more than 4/5 of the rows -- must still read zeros there)
-                gfull = m._scratch(("bwd", D, 0), (part.n_pad, D), torch.float32, zero=True)
+                # the operand of the next product: valid at the batch rows only (slots naming one node are summed); its
+                # flags are always consulted (count None), so the other rows are never read
+                gfull = m._scratch(("bwd", D, 0), (part.n_pad, D), torch.float32)
+                gfull.index_fill_(0, ctx.rows_p, 0.0)
                 gfull.index_add_(0, ctx.rows_p, g_top)
                 flags = torch.zeros(part.n_pad, dtype=torch.uint8, device=dev)
                 flags.index_fill_(0, ctx.rows_p, 1)
-                count = torch.full((1,), T, dtype=torch.int32, device=dev)
-                if not sparse:
-                    raise _lib.TagrecError("restricted sharded step needs the row-flag kernels")
-                operand = (gfull, flags, count)
-                head_rows = ctx.rows_p
+                operand = (gfull, flags, None)
             else:
                 gl = torch.empty_like(d_out)
                 fl = ops.rownorm_bwd_flags(raws[L - 1], invs[L - 1], d_out, s, gl) if sparse else None
@@ -409,26 +419,23 @@ class _ShardedLoss(torch.autograd.Function):
             first = n_pull - 1 if restricted else n_pull - 2          # index into raws of the layer the first hop lands on
             for k in range(first, -1, -1):
                 masked = restricted and k == n_pull - 1
-                gn = torch.zeros_like(d_out) if masked else torch.empty_like(d_out)
+                gn = torch.empty_like(d_out)                           # a masked hop writes the rows of the mask only
                 fo = None
                 if sparse:
                     fo = (torch.zeros if masked else torch.empty)(part.per, dtype=torch.uint8, device=dev)
-                gat = m._grad_gather(D, k & 1, sparse)
+                gat = m._grad_gather(D, k & 1, sparse, exact_flags=masked)
                 for c in range(part.n_chunks):
                     r = part.chunk_rows(c)
                     ops.layer_bwd(m.graph_chunks[c], operand[0], operand[1], operand[2], raws[k][r], invs[k][r], d_out[r], s,
-                                  gn[r], fo[r] if sparse else None, ctx.mid_mask[r] if masked else None)
+                                  gn[r], fo[r] if sparse else None, ctx.mid_mask[r] if masked else None,
+                                  dzf[r] if dzf is not None else None)
                     gat.put(c, gn[r], fo[r] if sparse else None)
-                if head_rows is not None:                      # the batch-row operand has been consumed: back to all-zero
-                    operand[0].index_fill_(0, head_rows, 0.0)
-                    head_rows = None
                 operand = gat.result()
             g0 = torch.empty_like(d_out)
             for c in range(part.n_chunks):
                 r = part.chunk_rows(c)
-                ops.last_hop(m.graph_chunks[c], operand[0], operand[1], operand[2], d_out[r], s, g0[r])
-            if head_rows is not None:
-                operand[0].index_fill_(0, head_rows, 0.0)
+                ops.last_hop(m.graph_chunks[c], operand[0], operand[1], operand[2], d_out[r], s, g0[r],
+                             dzf[r] if dzf is not None else None)
         g0.index_add_(0, ctx.loc, d_b[1][ctx.slot])                      # L2 term on the ego rows this rank owns
         ctx.raws = ctx.invs = ctx.y_top = None
         return g0, None, None
@@ -437,10 +444,11 @@ class _ShardedLoss(torch.autograd.Function):
 class _GradGather:
     """`_Gather` of a gradient block together with its row flags; result() = (table, flags, count) for the next product."""
 
-    def __init__(self, model, width, parity, sparse):
+    def __init__(self, model, width, parity, sparse, exact_flags=False):
         self.m = model
         self.g = _Gather(model, width, key=("bwd", parity))
         self.f = _Gather(model, None, torch.uint8, key=("bwdf", parity)) if sparse else None
+        self.exact = exact_flags          # the blocks were written on a row subset: rows flagged zero hold nothing valid
 
     def put(self, c, block, flags):
         self.g.put(c, block)
@@ -452,7 +460,7 @@ class _GradGather:
         if self.f is None:
             return full, None, None
         fl = self.f.table()
-        return full, fl, fl.sum(dtype=torch.int32).reshape(1)
+        return full, fl, (None if self.exact else fl.sum(dtype=torch.int32).reshape(1))
 
 
 class ShardedLightGCN(torch.nn.Module):
@@ -556,8 +564,8 @@ class ShardedLightGCN(torch.nn.Module):
             self._wait_end(e, name)
         return x
 
-    def _grad_gather(self, width, parity, sparse):
-        return _GradGather(self, width, parity, sparse)
+    def _grad_gather(self, width, parity, sparse, exact_flags=False):
+        return _GradGather(self, width, parity, sparse, exact_flags)
 
     def _gather_grad(self, g_local, flags_local, parity):
         gat = self._grad_gather(g_local.shape[1], parity, flags_local is not None)

@@ -120,12 +120,16 @@ def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0, masks=Non
 VEC_WIDTHS = (8, 16, 32, 64, 128, 256)
 
 
-def spmm_listed(graph, rows, x):
+def spmm_listed(graph, rows, x, out=None):
     """(A x)[rows] as a compact [len(rows), D] tensor (rows int64, may repeat)."""
     rows = rows.contiguous()
-    out = torch.empty(rows.numel(), x.shape[1], dtype=torch.float32, device=x.device)
-    graph._call("spmm_listed", _lib.load().tagrec_spmm_listed_f32, graph.handle, _lib.ptr(rows), rows.numel(), _lib.ptr(x),
-                _lib.ptr(out), x.shape[1], _lib.stream_ptr())
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(rows.numel(), x.shape[1], dtype=torch.float32, device=x.device)
+    ws_n = lib.tagrec_spmm_listed_workspace(rows.numel(), x.shape[1])
+    ws = torch.empty(max(ws_n, 1), dtype=torch.float32, device=x.device)
+    graph._call("spmm_listed", lib.tagrec_spmm_listed_f32, graph.handle, _lib.ptr(rows), rows.numel(), _lib.ptr(x),
+                _lib.ptr(out), x.shape[1], _lib.ptr(ws), ws_n, _lib.stream_ptr())
     return out
 
 

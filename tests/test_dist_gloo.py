@@ -40,17 +40,22 @@ class CpuOps:
         flags[(g.to_dense() != 0)[rows].any(0)] = 1
 
     def spmm_listed(self, g, rows, x, out):
-        out.copy_(g.to_dense()[rows] @ x)
+        w = g.to_dense()[rows]
+        used = (w != 0).any(0)                      # rows of x no listed row references may be unwritten
+        out.copy_(w[:, used] @ x[used])
 
     @staticmethod
     def _keep(row_mask, n):
         return torch.ones(n, dtype=torch.bool) if row_mask is None else row_mask.bool()
 
     @staticmethod
-    def _flagged(g_in, in_flags):
-        # the kernels MAY skip rows flagged zero and MAY read them (they stop consulting the flags once these cover 4/5
-        # of the rows): the caller must keep such rows zero.  Reading everything here checks that it does.
-        return g_in
+    def _flagged(g_in, in_flags, in_count):
+        # with a count the kernels MAY ignore the flags (they do once these cover 4/5 of the rows): the caller must keep
+        # rows flagged zero at zero -- reading everything here checks that it does.  Without a count the flags are always
+        # consulted and rows flagged zero may hold anything.
+        if in_flags is None or in_count is not None:
+            return g_in
+        return torch.where(in_flags.bool()[:, None], g_in, torch.zeros_like(g_in))
 
     def layer_fwd(self, g, xf, y, inv, acc, s, row_mask=None):
         full = g @ xf
@@ -58,17 +63,27 @@ class CpuOps:
         k = self._keep(row_mask, y.shape[0])
         y[k] = full[k]
         inv[k] = (1.0 / den)[k]
-        acc[k] += (s * full / den[:, None])[k]
+        if acc is not None:
+            acc[k] += (s * full / den[:, None])[k]
 
-    def layer_bwd(self, g, g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, row_mask=None):
-        res = g @ self._flagged(g_in, in_flags) + self._nb(x_raw, inv, s * dz)
+    def _nb_rows(self, x_raw, inv, dz, s, dz_flags):
+        if dz_flags is None:
+            return self._nb(x_raw, inv, s * dz)
+        f = dz_flags.bool()
+        out = torch.zeros_like(dz)
+        out[f] = self._nb(x_raw[f], inv[f], s * dz[f])
+        return out
+
+    def layer_bwd(self, g, g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, row_mask=None, dz_flags=None):
+        res = g @ self._flagged(g_in, in_flags, in_count) + self._nb_rows(x_raw, inv, dz, s, dz_flags)
         k = self._keep(row_mask, out.shape[0])
         out[k] = res[k]
         if out_flags is not None:
             out_flags[k] = (res[k] != 0).any(1).to(torch.uint8)
 
-    def last_hop(self, g, g_in, in_flags, in_count, b, s, out):
-        out.copy_(g @ self._flagged(g_in, in_flags) + s * b)
+    def last_hop(self, g, g_in, in_flags, in_count, b, s, out, b_flags=None):
+        bb = b if b_flags is None else torch.where(b_flags.bool()[:, None], b, torch.zeros_like(b))
+        out.copy_(g @ self._flagged(g_in, in_flags, in_count) + s * bb)
 
     def rownorm_fwd(self, x):
         den = x.norm(dim=1).clamp_min(1e-12)
