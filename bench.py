@@ -21,12 +21,12 @@ layers that need every row, the top layer in push form on the batch rows, flagge
 would carry every exchange): every rank holds D/N columns of every row plus the whole CSR; only row
 norms, row dot products and the B triplet scores are all-reduced.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused forward layer
-(`spmm_rows_kernel<16, NORM_ACC>`): algorithmic bytes per launch (SURVEY.md 8d:
-(8+4D) per stored entry + (8+4D) per row + 8D per row for the fused normalise/mean epilogue)
-divided by its mean duration from HIP events recorded on the launch stream inside the timed region.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused forward layer on all rows
+(`spmm_rows_kernel<16, NORM_ACC>`, run without the layer-mean accumulator: the training step forms the mean on the
+batch rows): algorithmic bytes per launch ((8+4D) per stored entry + (8+4D) per row + 4 per row for the
+norm) divided by its mean duration from HIP events recorded on the launch stream inside the timed region.
 `cpu_baseline` times the CPU oracle (PyTorch CPU restatement of the reference path, checked against
-the reference in tests/golden) on a 1/8-scale graph of the same shape and scales by stored entries.
+the reference in tests/golden) on the same graph and batch size, on the box's host cores.
 """
 import argparse
 import json
@@ -463,7 +463,9 @@ def main():
 
     # roofline of the dominant kernel: fused forward layer (local rows of this rank)
     dom = "spmm_norm_acc" if args.model == "lightgcn" else "spmm"
-    epi_row_bytes = 8 * D if args.model == "lightgcn" else 0
+    # LightGCN's training step forms the layer mean on the batch rows only, so its forward layers run the NORM_ACC
+    # epilogue WITHOUT the accumulator (acc = NULL): per row the product, its norm (4 B) and nothing else
+    epi_row_bytes = 4 if args.model == "lightgcn" else 0
     KF = cfg.get("factor_k", 1)
     if routed:
         dom = "route_spmm"
@@ -490,11 +492,12 @@ def main():
     if fwd:
         ms = sum(fwd) / len(fwd)
         ach = alg / (ms * 1e-3) / 1e9
-        kname = f"route_spmm_kernel<{D // 4}, {KF}>" if routed else f"spmm_rows_kernel<{Dl // 4}, {epi_name}>"
+        kname = (f"route_spmm_kernel<{D // 4}, {KF}>" if routed else
+                 f"spmm_rows_kernel<{Dl // 4}, {epi_name}{', acc = NULL' if epi_name == 'NORM_ACC' else ''}>")
         # compulsory bytes: every array of the launch touched exactly once (CSR, gathered table, outputs, accumulator
         # read-modify-write) -- what a perfect cache would leave for HBM
         comp = local_nnz * 8 + (n_local_rows + 1) * 8 + timed_graph.shape[1] * Dl * 4 + n_local_rows * Dl * 4
-        comp += {"NORM_ACC": n_local_rows * (8 * Dl + 4), "SS": n_local_rows * 4, "NONE": 0}[epi_name]
+        comp += {"NORM_ACC": n_local_rows * 4, "SS": n_local_rows * 4, "NONE": 0}[epi_name]
         roof = {"bound": "hbm", "kernel": kname + " (+ long-row finish)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source,
