@@ -13,12 +13,12 @@ sampled on the device beforehand (the reference also times its sampler separatel
 With N > 1 the SAME graph and batch are split over N ranks, one per GPU (strong scaling).  Launch either
 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` or as plain
 `python bench.py --gpus N`: the latter starts the N ranks itself (fresh child processes; the parent
-never touches the GPU).  `--parallel row` (default from 4 ranks): the node table, Adam state and CSR
+never touches the GPU).  `--parallel row` (default from 8 ranks): the node table, Adam state and CSR
 rows are sharded by row range -- the reference's split_adj_k folds (adj.py:114-140,158-164), one per GPU
 -- and the step is the restricted one of the single-GPU model: block-wise pipelined all-gathers of the
 layers that need every row, the top layer in push form on the batch rows, flagged gradient tables
-(tagrec_amd/dist.py).  `--parallel feature` (default at 2 ranks, where one xGMI link
-would carry every exchange): every rank holds D/N columns of every row plus the whole CSR; only row
+(tagrec_amd/dist.py).  `--parallel feature` (default up to 4 ranks, where the row partition's 4 table shards per step and link cost more
+than the step itself): every rank holds D/N columns of every row plus the whole CSR; only row
 norms, row dot products and the B triplet scores are all-reduced.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused forward layer on all rows
@@ -60,8 +60,8 @@ def parse():
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded model even with one rank (exercises dist.py + RCCL init on one GPU)")
     ap.add_argument("--parallel", choices=["auto", "feature", "row"], default="auto",
-                    help="multi-GPU sharding of the node table: row = row ranges (the reference's folds; default from 4 "
-                         "ranks), feature = columns (default at 2 ranks when dim / 2 >= 32)")
+                    help="multi-GPU sharding of the node table: row = row ranges (the reference's folds; default from 8 "
+                         "ranks), feature = columns (default up to 4 ranks when dim / ranks >= 16)")
     ap.add_argument("--chunks", type=int, default=0, help="row blocks per shard for the pipelined all-gathers (0 = default)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 and the ranks exchange "
@@ -344,10 +344,13 @@ def main():
     cfg = T.get_config(args.model, use_tag=False, dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B)
     parallel = args.parallel
     if parallel == "auto":
-        # 2 ranks share ONE xGMI link: a row partition would push ~3.5 tables per step through it, the column partition
-        # exchanges 50 MB and keeps 128-byte rows at D/2 >= 32.  From 4 ranks the row partition (the reference's folds)
-        # spreads the same bytes over 3 / 7 links and its per-rank product keeps full-width rows.
-        parallel = "feature" if (world == 2 and D % 2 == 0 and D // 2 >= 32) else "row"
+        # Byte budget of DESIGN.md section 6: the row partition (the reference's folds) sends 4 table shards per step over
+        # every xGMI link -- 1024 / 512 / 256 MB per link at 2 / 4 / 8 ranks for the 512 MB C2 table, i.e. ~16 / 8 / 4 ms at
+        # 64 GB/s -- against 6.6 / 3.5 / 1.9 ms of per-rank compute; the column partition exchanges ~50 MB per step but its
+        # gathers fall below the 128-byte line from 4 ranks on (D = 64).  Projected step: 2 ranks 20 vs 10 ms, 4 ranks 10.4
+        # vs 9.4 ms, 8 ranks 5.4 vs 9.3 ms (row vs column): columns up to 4 ranks, rows from 8.
+        col_ok = D % world == 0 and D // world >= 16
+        parallel = "feature" if (world <= 4 and col_ok) else "row"
     Dl = D // world if (sharded and parallel == "feature") else D
     if args.model != "lightgcn" and world > 1:
         sys.exit(f"bench.py: the sharded path covers LightGCN (C2/C5); run --model {args.model} on one GPU")

@@ -80,9 +80,13 @@ def propagate_forward(graph, x0, wps, dims, loss_rows=None):
             masks[L - 2] = graph.mark_rows(loss_rows, torch.zeros_like(top))
     for k, (w1p, w2p) in enumerate(wps):
         nei = graph.spmm_rows(x, torch.zeros_like(x), masks[k]) if k in masks else graph.spmm(x)
-        if k in masks and k == L - 1 and not torch.cuda.is_current_stream_capturing():      # (needs a host read)
-            # top layer: the dense block runs on the batch rows alone (one host read: their count)
-            rows = torch.unique(loss_rows)
+        if k in masks and k == L - 1:
+            # top layer: the dense block runs on the batch rows alone.  A node named by several batch slots is computed
+            # once per slot (identical values) and only its FIRST slot carries the upstream gradient in the backward
+            # pass, so the row list keeps its static length 3 B and nothing is read back to the host.
+            rows, _ = torch.sort(loss_rows)
+            first = torch.ones_like(rows, dtype=torch.bool)
+            first[1:] = rows[1:] != rows[:-1]
             xc, nc = x.index_select(0, rows), nei.index_select(0, rows)
             d = dims[k + 1]
             xpc = torch.empty(rows.numel(), d, dtype=torch.float32, device=x0.device)
@@ -90,12 +94,12 @@ def propagate_forward(graph, x0, wps, dims, loss_rows=None):
             zc = torch.empty(rows.numel(), d, dtype=torch.float32, device=x0.device)
             dense_forward(nc, xc, w1p, w2p, xpc, invc, zc, d)
             out[:, off:off + d].index_copy_(0, rows, zc)          # the other rows of this slot are never read
-            saved.append(("rows", rows, masks[k], masks.get(k - 1), xc, nc, xpc, invc, w1p, w2p))
+            saved.append(("rows", (rows, first), masks[k], masks.get(k - 1), xc, nc, xpc, invc, w1p, w2p))
             break
         xp = torch.empty(n, dims[k + 1], dtype=torch.float32, device=x0.device)
         inv = torch.empty(n, dtype=torch.float32, device=x0.device)
         dense_forward(nei, x, w1p, w2p, xp, inv, out[:, off:], dtot)
-        saved.append((x, nei, xp, inv, w1p, w2p))
+        saved.append((x, nei, xp, inv, w1p, w2p, masks.get(k), bool(masks)))
         x, off = xp, off + dims[k + 1]
     return out, saved
 
@@ -111,14 +115,14 @@ def propagate_backward(graph_t, d_out, saved, dims):
     dx_next = None
     for k in range(len(saved) - 1, -1, -1):
         if isinstance(saved[k][0], str):                       # the top layer of a restricted forward pass: batch rows only
-            _, rows, mask, reach, xc, nc, xpc, invc, w1p, w2p = saved[k]
+            _, (rows, first), mask, reach, xc, nc, xpc, invc, w1p, w2p = saved[k]
             d = dims[k + 1]
-            dzc = d_out[:, offs[k + 1]:offs[k + 1] + d].index_select(0, rows)
+            dzc = d_out[:, offs[k + 1]:offs[k + 1] + d].index_select(0, rows) * first[:, None]     # one slot per node
             d_nei_c, d_xd_c, dw1, dw2 = dense_backward(None, nc, xc, w1p, w2p, norm=(xpc, invc, dzc, d))
             dws[k] = (dw1, dw2)
             din = xc.shape[1]
-            d_nei = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_copy_(0, rows, d_nei_c)
-            d_xd = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_copy_(0, rows, d_xd_c)
+            d_nei = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_add_(0, rows, d_nei_c)
+            d_xd = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_add_(0, rows, d_xd_c)
             count = torch.full((1,), rows.numel(), dtype=torch.int32, device=xc.device)
             # d_nei and d_xd live on the batch rows, so dx is zero outside `reach` = those rows and their neighbours (the
             # mask the layer below was computed on): only they are visited
@@ -126,12 +130,21 @@ def propagate_backward(graph_t, d_out, saved, dims):
             graph_t.spmm_axpy_sparse(d_nei, mask, count, d_xd, 1.0, dx, reach)
             dx_next = dx
             continue
-        x, nei, xp, inv, w1p, w2p = saved[k]
+        x, nei, xp, inv, w1p, w2p, mask_k, restricted = saved[k]
         # d Xp = (what layer k+1 sent back) + normalize-backward of this layer's concat slot, formed inside the kernel
         d_nei, d_xd, dw1, dw2 = dense_backward(dx_next, nei, x, w1p, w2p, norm=(xp, inv, d_out[:, offs[k + 1]:], dtot))
         dws[k] = (dw1, dw2)
         dx = torch.empty_like(x)
-        if x.shape[1] in (8, 16, 32, 64, 128, 256):
+        if restricted and x.shape[1] in (8, 16, 32, 64, 128, 256):
+            # restricted forward: where d_nei can be non-zero is known without looking at it.  The layer computed on a
+            # row mask receives gradient on that mask only (the slot's dz lives on the batch rows, the layer above sends
+            # back onto `reach` = this mask): the mask serves as the row flags.  Below that nearly every row is reached
+            # through the popular items, and the plain product is used.
+            if mask_k is not None:
+                graph_t.spmm_axpy_sparse(d_nei, mask_k, None, d_xd, 1.0, dx)
+            else:
+                graph_t.spmm_axpy(d_nei, d_xd, 1.0, dx)
+        elif x.shape[1] in (8, 16, 32, 64, 128, 256):
             # d_nei is non-zero on the rows the batch gradient has reached so far (the batch rows in the last layer,
             # their neighbours one layer down): the product does not fetch the rows flagged zero (same result)
             flags = torch.empty(n, dtype=torch.uint8, device=x.device)
