@@ -233,6 +233,8 @@ def bench_tgcn(args):
         ach = alg / (m * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "tgcn_attn_fwd_kernel<32> (mean over the six relations)", "achieved": ach,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "traffic_source": "none: rocprofv3 averages a kernel over all its launches, and this step launches the kernel "
+                                  "on row subsets of varying size; per-kernel means of the step are in profiles/r02_pmc_c4_tgcn.csv",
                 "algorithmic_bytes_per_launch": alg, "mean_launch_ms": m, "launches_timed": len(fwd),
                 "measured_on": "one full forward pass over all rows, after the timed steps",
                 "all_rows_kernels_ms": {kk: sum(v) / len(v) for kk, v in full_ms.items() if kk != "attn_fwd"},
@@ -243,7 +245,8 @@ def bench_tgcn(args):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"C4 TGCN L={L} D={D} users={nu} items={ni} tags={nt} assignments={int(ds.uit_data.shape[0])} "
                                   f"k={k} train_batch={B} adam lr=0.01 logsigmoid", "train_batch": B, "parallelism": "single"},
-           "roofline": roof, "cpu_baseline": None,
+           "roofline": roof, "cpu_baseline": "not run (the reference cannot materialise this size: 4 M x (32 D + 48) floats "
+                                             "of convolution output per layer)",
            "extra": {"build_s": round(t_build, 1), "last_loss": [float(x) for x in last],
                      "transtag_step_ms": t_tt * 1e3,
                      "attention_ms_per_step": (sum(ms.get("attn_fwd", [])) + sum(ms.get("attn_bwd", []))) / K,
