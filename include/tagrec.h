@@ -132,6 +132,11 @@ int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G_in, const 
                                 const unsigned* in_count, const float* B, float b_scale, float* G_out,
                                 const uint8_t* row_mask /* may be NULL; as in spmm_normbwd_sparse */,
                                 const uint8_t* b_flags, int D, void* stream);
+/* G_out = A @ G_in on a row-sparse operand (in_flags / in_count as above; row_mask optional), writing the row flags of
+ * the result (out_flags; out_count optional).  The backward hop of a column-sharded table, whose normalize-backward term
+ * needs row dots over every rank's columns and is added on the batch rows by the caller. */
+int tagrec_spmm_flags_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags, const unsigned* in_count,
+                          float* G_out, uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask, int D, void* stream);
 /* Forward layer on a SUBSET of the output rows.  The loss reads the propagated table at the batch rows only
  * (model/lightgcn.py:71-75), so the last layer is needed on those rows and the layer below it on their neighbours.
  *   graph_mark_rows   : flags[c] = 1 for every column index stored in the listed rows and for the rows themselves

@@ -99,6 +99,7 @@ _SIGNATURES = {
                                       c_int, c_void_p],
     "tagrec_spmm_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_spmm_ss_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_spmm_flags_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tagrec_spmm_listed_workspace": [c_int64, c_int],
     "tagrec_spmm_listed_f32": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p],
     "tagrec_row_flags_f32": [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],

@@ -166,6 +166,10 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
   const int64_t off = r * LPR + (lane % LPR);  // float4 index of this lane's columns
   if constexpr (EPI == EPI_NONE) {
     if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
+    if (e.out_flags) {
+      const float nz = group_sum<LPR>((acc.x != 0.f || acc.y != 0.f || acc.z != 0.f || acc.w != 0.f) ? 1.f : 0.f);
+      if (lane == 0) e.out_flags[r] = nz != 0.f;
+    }
   } else if constexpr (EPI == EPI_NORM_ACC) {
     drop4(e.drop, off, acc.x, acc.y, acc.z, acc.w);
     const float ss = group_sum<LPR>(f4_dot(acc, acc));
@@ -769,6 +773,21 @@ extern "C" int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const f
   EpiArgs e{G_out, const_cast<float*>(inv_norm), nullptr, X_raw, dZ, dot, d_scale, DropMask{0.f, 0}, in_flags, in_count, out_flags, row_mask};
   int rc = launch_spmm<EPI_NORMBWD_DOT>(g, G_in, e, D, stream, "spmm_normbwd_dot_sparse");
   if (rc != TAGREC_OK || !out_flags) return rc;
+  return count_flags(out_flags, g->n_rows, out_count, static_cast<hipStream_t>(stream));
+}
+
+// Plain product on a row-sparse operand, writing the row flags of its result: the backward hop of a COLUMN-sharded table
+// (the normalize-backward term lives on the batch rows and needs row dots over every rank's columns, so the caller adds
+// it to those rows afterwards).
+extern "C" int tagrec_spmm_flags_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags, const unsigned* in_count,
+                                     float* G_out, uint8_t* out_flags, unsigned* out_count, const uint8_t* row_mask, int D,
+                                     void* stream) {
+  TAGREC_REQUIRE(in_flags != nullptr || in_count == nullptr, "spmm_flags: in_count without in_flags");
+  TAGREC_REQUIRE(out_flags != nullptr || out_count == nullptr, "spmm_flags: out_count without out_flags");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_flags: D must be 8 .. 256, a power of two");
+  EpiArgs e{G_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, in_flags, in_count, out_flags, row_mask, nullptr};
+  int rc = launch_spmm<EPI_NONE>(g, G_in, e, D, stream, "spmm_flags");
+  if (rc != TAGREC_OK || !out_count) return rc;
   return count_flags(out_flags, g->n_rows, out_count, static_cast<hipStream_t>(stream));
 }
 

@@ -126,6 +126,16 @@ class HipOps:
     def spmm_axpy(self, g, g_in, b, s, out):
         g.spmm_axpy(g_in, b, s, out)
 
+    def spmm_plain(self, g, x, y, row_mask=None):
+        """y = A x (rows of the mask only when given; the others are left unwritten)."""
+        if row_mask is None:
+            g.spmm(x, out=y)
+        else:
+            g.spmm_rows(x, y, row_mask)
+
+    def spmm_flags(self, g, g_in, in_flags, in_count, out, out_flags, row_mask=None):
+        g.spmm_flags(g_in, in_flags, in_count, out, out_flags, None, row_mask)
+
     def spmm_ss(self, g, x, y, ss):
         g._call("spmm_ss", _lib.load().tagrec_spmm_ss_f32, g.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(ss), x.shape[1],
                 _lib.stream_ptr())
@@ -602,6 +612,100 @@ class ShardedLightGCN(torch.nn.Module):
 
 
 # ====================================================================================== feature sharding
+class _FeatureRestrictedLoss(torch.autograd.Function):
+    """The restricted training step (lightgcn.restricted_forward / _backward) on a COLUMN slice of the table.
+
+    Products are independent per column, so the chain runs without any exchange.  What reduces over a row's columns is
+    needed at the <= 3 B batch rows only -- the layer mean is read there, and so are the normalize-backward terms -- so
+    three small all-reduces replace the two [L, N] ones of the all-rows step: squared norms [L, 3B], triplet dots
+    [B, 3], normalize-backward dots [L, 3B]."""
+
+    @staticmethod
+    def forward(ctx, table, model, trip):
+        m, ops = model, model.ops
+        x0 = table.detach()
+        L, s = m.num_layer, 1.0 / (m.num_layer + 1)
+        n, Dl = x0.shape
+        B = trip.shape[0]
+        dev = x0.device
+        rows = torch.cat([trip[:, 0], m.n_user + trip[:, 1], m.n_user + trip[:, 2]])
+        mid = ops.mark_rows(m.graph, rows, torch.zeros(n, dtype=torch.uint8, device=dev)) if L >= 2 else None
+        raws = []
+        x = x0
+        for k in range(L - 1):
+            y = torch.empty_like(x0)                       # rows outside the mask stay unwritten; nothing reads them
+            ops.spmm_plain(m.graph, x, y, mid if k == L - 2 else None)
+            raws.append(y)
+            x = y
+        y_top = torch.empty(rows.numel(), Dl, dtype=torch.float32, device=dev)
+        ops.spmm_listed(m.graph, rows, x, y_top)
+        at_rows = [y.index_select(0, rows) for y in raws] + [y_top]          # [T, Dl] per layer
+        ss = torch.stack([(a * a).sum(1) for a in at_rows])                  # local columns' share of the squared norms
+        m.all_reduce(ss)
+        inv = 1.0 / torch.sqrt(ss).clamp_min(1e-12)                          # [L, T]
+        ego_b = x0.index_select(0, rows)
+        out_b = ego_b * s
+        for a, iv in zip(at_rows, inv):
+            out_b.addcmul_(a, iv[:, None], value=s)
+        ar = torch.arange(B, device=dev)
+        ctrip = torch.stack([ar, ar, ar + B], dim=1).contiguous()
+        dots = ops.bpr_dots(out_b[:B], out_b[B:], ego_b[:B], ego_b[B:], ctrip)
+        m.all_reduce(dots)                                                   # full-width scores and L2 term
+        xd = dots[:, 1] - dots[:, 0]                                         # neg - pos
+        if m.loss_func == "logsigmoid":
+            loss = -torch.nn.functional.logsigmoid(-xd).mean()
+            coef = torch.sigmoid(xd)
+        else:
+            loss = torch.nn.functional.softplus(xd).mean()
+            coef = torch.where(xd > 20.0, torch.ones_like(xd), torch.sigmoid(xd))
+        ctx.m, ctx.raws, ctx.mid, ctx.rows, ctx.at_rows, ctx.inv = m, raws, mid, rows, at_rows, inv
+        ctx.out_b, ctx.ego_b, ctx.ctrip, ctx.coef, ctx.shape = out_b, ego_b, ctrip, coef.contiguous(), x0.shape
+        return torch.stack([loss, dots[:, 2].sum() / B])
+
+    @staticmethod
+    def backward(ctx, g):
+        m, ops, raws, rows, mid = ctx.m, ctx.m.ops, ctx.raws, ctx.rows, ctx.mid
+        L, s = m.num_layer, 1.0 / (m.num_layer + 1)
+        n, Dl = ctx.shape
+        B = ctx.ctrip.shape[0]
+        T = rows.numel()
+        dev = ctx.out_b.device
+        g = g.contiguous()
+        out_b, ego_b = ctx.out_b, ctx.ego_b
+        d_b = torch.zeros(2, T, Dl, dtype=torch.float32, device=dev)          # d / d out_b, d / d ego_b (local columns)
+        reg = m.reg != 0
+        ops.bpr_bwd(out_b[:B], out_b[B:], ego_b[:B] if reg else None, ego_b[B:] if reg else None, ctx.ctrip, ctx.coef, g,
+                    d_b[0][:B], d_b[0][B:], d_b[1][:B] if reg else None, d_b[1][B:] if reg else None)
+        dz = d_b[0] * s                                                       # gradient w.r.t. each normalised layer, per slot
+        # normalize-backward of every layer at the batch slots: nb = inv (dz - z (z . dz)), the dot over ALL columns
+        zs = [a * iv[:, None] for a, iv in zip(ctx.at_rows, ctx.inv)]
+        dot = torch.stack([(z * dz).sum(1) for z in zs])
+        m.all_reduce(dot)
+        dot = torch.where(ctx.inv >= 1e12, torch.zeros_like(dot), dot)        # the clamp is constant where ||x|| <= eps
+        nb = [iv[:, None] * (dz - z * d[:, None]) for z, iv, d in zip(zs, ctx.inv, dot)]
+        tflag = torch.zeros(n, dtype=torch.uint8, device=dev)
+        tflag.index_fill_(0, rows, 1)
+        gcur = torch.empty(n, Dl, dtype=torch.float32, device=dev)            # G^L: valid on the batch rows only
+        gcur.index_fill_(0, rows, 0.0)
+        gcur.index_add_(0, rows, nb[L - 1])
+        flags, count = tflag, None
+        for k in range(L - 2, -1, -1):
+            masked = k == L - 2
+            gn = torch.empty(n, Dl, dtype=torch.float32, device=dev)
+            fo = (torch.zeros if masked else torch.empty)(n, dtype=torch.uint8, device=dev)
+            ops.spmm_flags(m.graph, gcur, flags, count, gn, fo, mid if masked else None)
+            gn.index_add_(0, rows, nb[k])                  # (batch rows lie inside the mask: the product wrote them)
+            fo.index_fill_(0, rows, 1)
+            gcur, flags, count = gn, fo, None              # flags always consulted: a masked hop wrote its mask only
+        g0 = torch.empty(n, Dl, dtype=torch.float32, device=dev)
+        ops.spmm_flags(m.graph, gcur, flags, count, g0, None, None)
+        g0.index_add_(0, rows, dz)                          # the ego layer's share of the mean
+        if reg:
+            g0.index_add_(0, rows, d_b[1])
+        ctx.raws = ctx.at_rows = None
+        return g0, None, None
+
+
 class _FeatureShardedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, model, trip):
@@ -714,6 +818,11 @@ class FeatureShardedLightGCN(torch.nn.Module):
         self.dim_local = self.dim_latent // self.world
         self.reg = config["reg"]
         self.loss_func = config["mul_loss_func"]
+        self.restrict_forward = bool(config.get("restrict_forward", True))
+        if config.get("norm_type", "bi_norm") not in ("bi_norm", "plain"):
+            raise _lib.TagrecError(
+                f"FeatureShardedLightGCN: norm_type {config.get('norm_type')!r} is not symmetric; the backward products use "
+                "the same matrix as the forward ones (use bi_norm, or the single-GPU model)")
         self.n_user, self.n_item = data.num["user"], data.num["item"]
         self.n_nodes = int(n_nodes)
         self.graph = self.ops.make_graph(rowptr, col, val, (self.n_nodes, self.n_nodes))
@@ -730,9 +839,15 @@ class FeatureShardedLightGCN(torch.nn.Module):
             dist.all_reduce(x, group=self.group)
         return x
 
+    restrict_min_ratio = 16          # the restricted step is used when 3 B * this <= number of nodes
+
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
-        res = _FeatureShardedLoss.apply(self.table, self, batch_data)
+        restricted = (self.restrict_forward and getattr(self.ops, "restrict_forward", False) and self.num_layer >= 1
+                      and self.dim_local in (8, 16, 32, 64, 128, 256)
+                      and 3 * batch_data.shape[0] * self.restrict_min_ratio <= self.n_nodes)
+        fn = _FeatureRestrictedLoss if restricted else _FeatureShardedLoss
+        res = fn.apply(self.table, self, batch_data)
         return res[0], self.reg * res[1]
 
     def gathered_table(self):

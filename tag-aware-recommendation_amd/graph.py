@@ -385,6 +385,14 @@ class Graph:
                    _lib.ptr(g_in), _lib.ptr(in_flags), _lib.ptr(in_count), _lib.ptr(b), float(b_scale), _lib.ptr(g_out),
                    _lib.ptr(row_mask), _lib.ptr(b_flags), D, _lib.stream_ptr())
 
+    def spmm_flags(self, g_in, in_flags, in_count, g_out, out_flags, out_count=None, row_mask=None):
+        """g_out = A @ g_in on a row-sparse operand (in_count None: flags always consulted), row flags of the result written
+        to out_flags; row_mask: only these rows are computed / written."""
+        D = self._chk_x(g_in, self.shape[1], "spmm_flags g_in")
+        self._call("spmm_flags_rows" if row_mask is not None else "spmm_flags", _lib.load().tagrec_spmm_flags_f32, self._h,
+                   _lib.ptr(g_in), _lib.ptr(in_flags), _lib.ptr(in_count), _lib.ptr(g_out), _lib.ptr(out_flags),
+                   _lib.ptr(out_count), _lib.ptr(row_mask), D, _lib.stream_ptr())
+
     def spmm_axpy(self, g_in, b, b_scale, g_out):
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy g_in")
         for t, nm in ((b, "b"), (g_out, "g_out")):

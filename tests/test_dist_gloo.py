@@ -137,6 +137,17 @@ class CpuOps:
     def spmm_axpy(self, g, g_in, b, s, out):
         out.copy_(g @ g_in + s * b)
 
+    def spmm_plain(self, g, x, y, row_mask=None):
+        k = self._keep(row_mask, y.shape[0])
+        y[k] = (g @ x)[k]
+
+    def spmm_flags(self, g, g_in, in_flags, in_count, out, out_flags, row_mask=None):
+        res = g @ self._flagged(g_in, in_flags, in_count)
+        k = self._keep(row_mask, out.shape[0])
+        out[k] = res[k]
+        if out_flags is not None:
+            out_flags[k] = (res[k] != 0).any(1).to(torch.uint8)
+
     def spmm_ss(self, g, x, y, ss):
         y.copy_(g @ x)
         ss.copy_((y * y).sum(1))
@@ -167,7 +178,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _feature_worker(rank, world, port, out_dir):
+def _feature_worker(rank, world, port, out_dir, n_layer, restrict):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -179,11 +190,13 @@ def _feature_worker(rank, world, port, out_dir):
     try:
         fx = load_golden("lightgcn_toy")
         csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "bi_norm")
-        cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64, 64], reg=float(fx["reg"]), device="cpu")
+        cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64] * n_layer, reg=float(fx["reg"]), device="cpu")
         ds = T.synth.Dataset()
         ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
         m = TD.FeatureShardedLightGCN(ds, cfg, torch.from_numpy(csr.rowptr), torch.from_numpy(csr.col),
                                       torch.from_numpy(csr.val), csr.shape[0], ops=CpuOps())
+        m.restrict_forward = restrict
+        m.restrict_min_ratio = 0                  # the toy batches touch most rows: force the restricted step when asked
         full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)])
         lo = rank * m.dim_local
         with torch.no_grad():
@@ -202,24 +215,31 @@ def _feature_worker(rank, world, port, out_dir):
             opt.step()
         table = m.gathered_table()
         if rank == 0:
-            np.savez(os.path.join(out_dir, f"f{world}.npz"), losses=np.array(losses), grad0=grad0.numpy(), table=table.numpy())
+            np.savez(os.path.join(out_dir, "feat.npz"), losses=np.array(losses), grad0=grad0.numpy(), table=table.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_feature_sharded_lightgcn_matches_single_process(tmp_path, golden, world):
-    """Column-sharded tables: per-column SpMM, all-reduced row norms / row dots / triplet scores."""
+@pytest.mark.parametrize("world,n_layer,restrict", [(2, 2, False), (4, 2, False), (2, 2, True), (4, 2, True), (2, 3, True),
+                                                     (4, 1, True), (8, 3, True)])
+def test_feature_sharded_lightgcn_matches_single_process(tmp_path, golden, world, n_layer, restrict):
+    """Column-sharded tables: per-column products; all-rows step = all-reduced row norms / row dots / triplet scores over
+    [L, N]; restricted step = the same quantities on the 3 B batch rows only."""
     port = _free_port()
-    mp.spawn(_feature_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    got = np.load(tmp_path / f"f{world}.npz")
+    mp.spawn(_feature_worker, args=(world, port, str(tmp_path), n_layer, restrict), nprocs=world, join=True)
+    got = np.load(tmp_path / "feat.npz")
     fx = golden("lightgcn_toy")
-    np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
-    np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=1e-5)
-    want_g = np.concatenate([fx[f"grad.embed.{t}"] for t in range(3)])
-    np.testing.assert_allclose(got["grad0"], want_g, rtol=1e-3, atol=1e-8)
-    want_t = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
-    assert np.abs(got["table"] - want_t).max() <= 2e-4
+    if n_layer == 2:
+        np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
+        np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=1e-5)
+        want_g = np.concatenate([fx[f"grad.embed.{t}"] for t in range(3)])
+        np.testing.assert_allclose(got["grad0"], want_g, rtol=1e-3, atol=1e-8)
+        want_t = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
+        assert np.abs(got["table"] - want_t).max() <= 2e-4
+    losses, grad0, table, _ = _single_process(fx, n_layer)
+    np.testing.assert_allclose(got["losses"], losses, rtol=1e-5)
+    np.testing.assert_allclose(got["grad0"], grad0, rtol=1e-3, atol=1e-8)
+    assert np.abs(got["table"] - table).max() <= 2e-4
 
 
 def _row_model(rank, world, fx, n_layer, n_chunks, restrict, norm="bi_norm"):

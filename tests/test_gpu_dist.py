@@ -42,8 +42,10 @@ def _worker(rank, world, port, out_dir, kind, fixture="lightgcn_toy"):
         args = (ds, cfg, torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.col).to(dev), torch.from_numpy(csr.val).to(dev),
                 csr.shape[0])
         full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)]).to(dev)
-        if kind == "feature":
+        if kind.startswith("feature"):
             m = TD.FeatureShardedLightGCN(*args)
+            if kind == "feature_restricted":
+                m.restrict_min_ratio = 0
             lo = rank * m.dim_local
             with torch.no_grad():
                 m.table.copy_(full[:, lo:lo + m.dim_local])
@@ -72,7 +74,8 @@ def _worker(rank, world, port, out_dir, kind, fixture="lightgcn_toy"):
 
 @pytest.mark.parametrize("kind,fixture", [("feature", "lightgcn_toy"), ("row", "lightgcn_toy"), ("row_restricted", "lightgcn_toy"),
                                           ("row_restricted", "lightgcn_toy_d256"), ("row", "lightgcn_toy_d256"),
-                                          ("feature", "lightgcn_toy_d256")])
+                                          ("feature", "lightgcn_toy_d256"), ("feature_restricted", "lightgcn_toy"),
+                                          ("feature_restricted", "lightgcn_toy_d256")])
 def test_two_ranks_real_kernels(tmp_path, golden, kind, fixture):
     """Three Adam steps on two ranks against the parameters the REFERENCE reached (golden `step3`); the d256 fixture is
     C5's row width (3 layers), where the restricted row-sharded step uses all of: full layer, masked layer, push-form top."""
@@ -86,7 +89,13 @@ def test_two_ranks_real_kernels(tmp_path, golden, kind, fixture):
     assert np.abs(got["table"] - want).max() <= 2e-4
 
 
-def _mid_worker(rank, world, port, out_dir, D, n_chunks, n_layer):
+def _all_gather_list(t, world):
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous())
+    return parts
+
+
+def _mid_worker(rank, world, port, out_dir, D, n_chunks, n_layer, kind="row"):
     import sys
     sys.path.insert(0, ROOT)
     import tagrec_amd as T
@@ -104,21 +113,30 @@ def _mid_worker(rank, world, port, out_dir, D, n_chunks, n_layer):
         ref = T.LightGCN(ds, config=cfg, graph=T.Graph(rp, col, val, (n, n), symmetric=True))
         ref.train()
         ref.restrict_forward = False                   # the reference point: every layer on all rows, one GPU
-        sm = TD.ShardedLightGCN(ds, cfg, rp, col, val, n, n_chunks=n_chunks)
+        if kind == "feature":
+            sm = TD.FeatureShardedLightGCN(ds, cfg, rp, col, val, n)
+            lo = rank * sm.dim_local
+            with torch.no_grad():
+                sm.table.copy_(ref.table[:, lo:lo + sm.dim_local])
+            gather_grad = lambda t: torch.cat(_all_gather_list(t, world), dim=1)
+        else:
+            sm = TD.ShardedLightGCN(ds, cfg, rp, col, val, n, n_chunks=n_chunks)
+            with torch.no_grad():
+                sm.table.zero_()
+                hi = min(sm.hi, n)
+                sm.table[:hi - sm.lo] = ref.table[sm.lo:hi]
+            gather_grad = lambda t: sm.all_gather(t)[:n]
         assert 3 * B * sm.restrict_min_ratio <= n       # the restricted sharded step is what runs
-        with torch.no_grad():
-            sm.table.zero_()
-            hi = min(sm.hi, n)
-            sm.table[:hi - sm.lo] = ref.table[sm.lo:hi]
         batches = T.BPR_training_data(ds, config=cfg, seed=1).all_train_data
         o1, o2 = T.Adam(ref.parameters(), lr=0.01), T.Adam(sm.parameters(), lr=0.01)
         rec = {}
-        u, i = sm.forward()                            # evaluation path: every layer on all rows, gathered tables
-        ref.eval()
-        with torch.no_grad():
-            ru, ri = ref.forward()
-        ref.train()
-        rec["u1"], rec["u2"], rec["i1"], rec["i2"] = ru.cpu().numpy(), u.cpu().numpy(), ri.cpu().numpy(), i.cpu().numpy()
+        if kind == "row":
+            u, i = sm.forward()                        # evaluation path: every layer on all rows, gathered tables
+            ref.eval()
+            with torch.no_grad():
+                ru, ri = ref.forward()
+            ref.train()
+            rec["u1"], rec["u2"], rec["i1"], rec["i2"] = ru.cpu().numpy(), u.cpu().numpy(), ri.cpu().numpy(), i.cpu().numpy()
         for step in range(2):
             b = batches[step * B:(step + 1) * B]
             l1, l2 = ref.loss(b), sm.loss(b)
@@ -126,7 +144,7 @@ def _mid_worker(rank, world, port, out_dir, D, n_chunks, n_layer):
             sum(l1).backward(); sum(l2).backward()
             rec[f"l1_{step}"] = np.array([float(v) for v in l1]); rec[f"l2_{step}"] = np.array([float(v) for v in l2])
             rec[f"g1_{step}"] = ref.table.grad.cpu().numpy()
-            rec[f"g2_{step}"] = sm.all_gather(sm.table.grad)[:n].cpu().numpy()
+            rec[f"g2_{step}"] = gather_grad(sm.table.grad).cpu().numpy()
             o1.step(); o2.step()
         rec["t1"], rec["t2"] = ref.table.detach().cpu().numpy(), sm.gathered_table().cpu().numpy()
         if rank == 0:
@@ -135,14 +153,16 @@ def _mid_worker(rank, world, port, out_dir, D, n_chunks, n_layer):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("D,n_chunks,n_layer", [(64, 2, 3), (256, 3, 3), (64, 1, 2)])
-def test_row_sharded_restricted_step_equals_single_gpu_model(tmp_path, D, n_chunks, n_layer):
+@pytest.mark.parametrize("D,n_chunks,n_layer,kind", [(64, 2, 3, "row"), (256, 3, 3, "row"), (64, 1, 2, "row"),
+                                                      (64, 1, 3, "feature"), (256, 1, 3, "feature"), (64, 1, 1, "feature")])
+def test_sharded_restricted_step_equals_single_gpu_model(tmp_path, D, n_chunks, n_layer, kind):
     """Two ranks (both on cuda:0, exchanging through gloo), real kernels, a graph large enough for the restricted sharded
-    step (pipelined block all-gathers, masked layer, push-form top layer, flagged gradient tables): losses, table
-    gradients, tables after two Adam steps and the propagated tables of the one-GPU model computed on ALL rows.
-    D = 256 is the C5 row width."""
+    step -- rows: pipelined block all-gathers, masked layer, push-form top layer, flagged gradient tables; columns: the
+    single-GPU restricted chain per column slice with the row norms / dots of the batch rows all-reduced -- against the
+    one-GPU model computed on ALL rows: losses, table gradients, tables after two Adam steps (and, rows, the propagated
+    tables).  D = 256 is the C5 row width."""
     port = _free_port()
-    mp.spawn(_mid_worker, args=(2, port, str(tmp_path), D, n_chunks, n_layer), nprocs=2, join=True)
+    mp.spawn(_mid_worker, args=(2, port, str(tmp_path), D, n_chunks, n_layer, kind), nprocs=2, join=True)
     r = np.load(tmp_path / "mid.npz")
     for step in range(2):
         np.testing.assert_allclose(r[f"l2_{step}"], r[f"l1_{step}"], rtol=5e-6)
@@ -152,8 +172,9 @@ def test_row_sharded_restricted_step_equals_single_gpu_model(tmp_path, D, n_chun
         np.testing.assert_allclose(g2, g1, rtol=1e-3, atol=1e-5 * np.abs(g1).max())
     # Adam turns last-bit gradient differences of near-zero entries into lr-sized steps
     assert np.abs(r["t2"] - r["t1"]).max() <= 2e-4 * 2
-    np.testing.assert_allclose(r["u2"], r["u1"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(r["i2"], r["i1"], rtol=1e-4, atol=1e-5)
+    if kind == "row":
+        np.testing.assert_allclose(r["u2"], r["u1"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(r["i2"], r["i1"], rtol=1e-4, atol=1e-5)
 
 
 def test_bench_starts_its_own_ranks():

@@ -426,14 +426,14 @@ def test_feature_sharded_restricted_step_equals_single_gpu_model():
     m.train()
     m.restrict_forward = False
     batch = T.BPR_training_data(ds, config=cfg, seed=1).all_train_data[:128]
-    assert batch.shape[0] * 48 <= n
+    assert 3 * batch.shape[0] * 16 <= n
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29574")
         dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         sm = TD.FeatureShardedLightGCN(ds, cfg, rp, col, val, n)
-        assert sm.ops.restrict_forward and sm.ops.sparse_backward
+        assert sm.ops.restrict_forward and sm.restrict_forward          # the restricted column-sharded step is what runs
         with torch.no_grad():
             sm.table.copy_(m.table)
         l1, l2 = m.loss(batch), sm.loss(batch)
