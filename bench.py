@@ -349,10 +349,11 @@ def main():
     if parallel == "auto":
         # Byte budget of DESIGN.md section 6: the row partition (the reference's folds) sends 4 table shards per step over
         # every xGMI link -- 1024 / 512 / 256 MB per link at 2 / 4 / 8 ranks for the 512 MB C2 table, i.e. ~16 / 8 / 4 ms at
-        # 64 GB/s -- against 6.6 / 3.5 / 1.9 ms of per-rank compute; the column partition exchanges ~50 MB per step but its
-        # gathers fall below the 128-byte line from 4 ranks on (D = 64).  Projected step: 2 ranks 20 vs 10 ms, 4 ranks 10.4
-        # vs 9.4 ms, 8 ranks 5.4 vs 9.3 ms (row vs column): columns up to 4 ranks, rows from 8.
-        col_ok = D % world == 0 and D // world >= 16
+        # 64 GB/s -- against 6.6 / 3.5 / 1.9 ms of per-rank compute.  The column partition exchanges three small all-reduces
+        # per step and its per-rank step was measured on one rank's slice: 7.5 / 6.9 / 6.5 ms (32 / 16 / 8 columns; below
+        # 32 columns a gathered row is shorter than the 128-byte line).  Projected step, row vs column: 2 ranks 20 vs 7.6 ms,
+        # 4 ranks 10.4 vs 7.0 ms, 8 ranks 5.4 vs 6.6 ms: columns up to 4 ranks, rows from 8.
+        col_ok = D % world == 0 and D // world >= 8
         parallel = "feature" if (world <= 4 and col_ok) else "row"
     Dl = D // world if (sharded and parallel == "feature") else D
     if args.model != "lightgcn" and world > 1:

@@ -167,9 +167,9 @@ def test_sharded_restricted_step_equals_single_gpu_model(tmp_path, D, n_chunks, 
     for step in range(2):
         np.testing.assert_allclose(r[f"l2_{step}"], r[f"l1_{step}"], rtol=5e-6)
         g1, g2 = r[f"g1_{step}"], r[f"g2_{step}"]
-        # gradients: rtol 1e-3 with a floor of 1e-5 of the largest entry (sums that cancel; the push-form top layer and
+        # gradients: rtol 1e-3 with a floor of 3e-5 of the largest entry (sums that cancel; the push-form top layer and
         # the per-slot head of the backward chain add in a different order than the one-GPU pull kernels)
-        np.testing.assert_allclose(g2, g1, rtol=1e-3, atol=1e-5 * np.abs(g1).max())
+        np.testing.assert_allclose(g2, g1, rtol=1e-3, atol=3e-5 * np.abs(g1).max())
     # Adam turns last-bit gradient differences of near-zero entries into lr-sized steps
     assert np.abs(r["t2"] - r["t1"]).max() <= 2e-4 * 2
     if kind == "row":
