@@ -58,7 +58,30 @@ def dense_backward(dxp, nei, x, w1p, w2p, norm=None):
 RESTRICT_FORWARD = True     # loss(): form the top two layers' neighbour sums only on the rows the batch's loss depends on
 
 
-def propagate_forward(graph, x0, wps, dims, loss_rows=None):
+def _layer_seed(seed, k):
+    return (int(seed) * 64 + k) & 0xFFFFFFFFFFFFFFFF
+
+
+def _drop_renorm(xp, inv, z_slot, ldz, p, seed):
+    """Message dropout of a layer's output (ngcf.py:85) behind the fused dense kernel: Xp <- mask(seed) Xp / (1 - p) with the
+    library's counter-based mask, then the slot of the concatenated output and the inverse norms are recomputed from it
+    (two element-wise passes; the MFMA kernels stay in use)."""
+    H.message_drop(xp, p, seed, out=xp)
+    n, d = xp.shape
+    _lib.check(_lib.load().tagrec_rownorm_fwd_f32(_lib.ptr(xp), _lib.ptr(z_slot), ldz, _lib.ptr(inv), n, d, _lib.stream_ptr()),
+               "rownorm_fwd")
+
+
+def _dxp_through_dropout(dx_next, xp, inv, dz, ldz, p, seed):
+    """d loss / d (pre-dropout Xp) = mask / (1 - p) * (dx_next + normalize-backward(Xp_dropped, inv, dz))."""
+    n, d = xp.shape
+    g = torch.zeros_like(xp) if dx_next is None else dx_next.contiguous().clone()
+    _lib.check(_lib.load().tagrec_rownorm_bwd_f32(_lib.ptr(xp), _lib.ptr(inv), _lib.ptr(dz), ldz, 1.0, _lib.ptr(g), 1, n, d,
+                                                  _lib.stream_ptr()), "rownorm_bwd")
+    return H.message_drop(g, p, seed, out=g)
+
+
+def propagate_forward(graph, x0, wps, dims, loss_rows=None, drops=None, seed=0):
     """x0 [N, dims[0]] -> out [N, sum(dims)] = cat(x0, z1..zL) and the per-layer state for backward.
 
     loss_rows (int64 node ids): `out` will be read at these rows only (the batch rows).  Then the last layer's
@@ -93,13 +116,19 @@ def propagate_forward(graph, x0, wps, dims, loss_rows=None):
             invc = torch.empty(rows.numel(), dtype=torch.float32, device=x0.device)
             zc = torch.empty(rows.numel(), d, dtype=torch.float32, device=x0.device)
             dense_forward(nc, xc, w1p, w2p, xpc, invc, zc, d)
+            pk = drops[k] if drops else 0.0
+            if pk > 0:                                             # (the mask is indexed by the position in this row list)
+                _drop_renorm(xpc, invc, zc, d, pk, _layer_seed(seed, k))
             out[:, off:off + d].index_copy_(0, rows, zc)          # the other rows of this slot are never read
-            saved.append(("rows", (rows, first), masks[k], masks.get(k - 1), xc, nc, xpc, invc, w1p, w2p))
+            saved.append(("rows", (rows, first), masks[k], masks.get(k - 1), xc, nc, xpc, invc, w1p, w2p, pk, _layer_seed(seed, k)))
             break
         xp = torch.empty(n, dims[k + 1], dtype=torch.float32, device=x0.device)
         inv = torch.empty(n, dtype=torch.float32, device=x0.device)
         dense_forward(nei, x, w1p, w2p, xp, inv, out[:, off:], dtot)
-        saved.append((x, nei, xp, inv, w1p, w2p, masks.get(k), bool(masks)))
+        pk = drops[k] if drops else 0.0
+        if pk > 0:
+            _drop_renorm(xp, inv, out[:, off:], dtot, pk, _layer_seed(seed, k))
+        saved.append((x, nei, xp, inv, w1p, w2p, masks.get(k), bool(masks), pk, _layer_seed(seed, k)))
         x, off = xp, off + dims[k + 1]
     return out, saved
 
@@ -115,10 +144,13 @@ def propagate_backward(graph_t, d_out, saved, dims):
     dx_next = None
     for k in range(len(saved) - 1, -1, -1):
         if isinstance(saved[k][0], str):                       # the top layer of a restricted forward pass: batch rows only
-            _, (rows, first), mask, reach, xc, nc, xpc, invc, w1p, w2p = saved[k]
+            _, (rows, first), mask, reach, xc, nc, xpc, invc, w1p, w2p, pk, sk = saved[k]
             d = dims[k + 1]
             dzc = d_out[:, offs[k + 1]:offs[k + 1] + d].index_select(0, rows) * first[:, None]     # one slot per node
-            d_nei_c, d_xd_c, dw1, dw2 = dense_backward(None, nc, xc, w1p, w2p, norm=(xpc, invc, dzc, d))
+            if pk > 0:
+                d_nei_c, d_xd_c, dw1, dw2 = dense_backward(_dxp_through_dropout(None, xpc, invc, dzc, d, pk, sk), nc, xc, w1p, w2p)
+            else:
+                d_nei_c, d_xd_c, dw1, dw2 = dense_backward(None, nc, xc, w1p, w2p, norm=(xpc, invc, dzc, d))
             dws[k] = (dw1, dw2)
             din = xc.shape[1]
             d_nei = torch.zeros(n, din, dtype=torch.float32, device=xc.device).index_add_(0, rows, d_nei_c)
@@ -130,9 +162,14 @@ def propagate_backward(graph_t, d_out, saved, dims):
             graph_t.spmm_axpy_sparse(d_nei, mask, count, d_xd, 1.0, dx, reach)
             dx_next = dx
             continue
-        x, nei, xp, inv, w1p, w2p, mask_k, restricted = saved[k]
+        x, nei, xp, inv, w1p, w2p, mask_k, restricted, pk, sk = saved[k]
         # d Xp = (what layer k+1 sent back) + normalize-backward of this layer's concat slot, formed inside the kernel
-        d_nei, d_xd, dw1, dw2 = dense_backward(dx_next, nei, x, w1p, w2p, norm=(xp, inv, d_out[:, offs[k + 1]:], dtot))
+        # (with message dropout: formed outside, masked, and handed to the kernel as dXp)
+        if pk > 0:
+            d_nei, d_xd, dw1, dw2 = dense_backward(_dxp_through_dropout(dx_next, xp, inv, d_out[:, offs[k + 1]:], dtot, pk, sk),
+                                                   nei, x, w1p, w2p)
+        else:
+            d_nei, d_xd, dw1, dw2 = dense_backward(dx_next, nei, x, w1p, w2p, norm=(xp, inv, d_out[:, offs[k + 1]:], dtot))
         dws[k] = (dw1, dw2)
         dx = torch.empty_like(x)
         if restricted and x.shape[1] in (8, 16, 32, 64, 128, 256):
@@ -172,8 +209,8 @@ def _wps(mats):
 
 class _Propagate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, graph, dims, table, *mats):
-        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims)
+    def forward(ctx, graph, dims, drops, seed, table, *mats):
+        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims, None, drops, seed)
         ctx.graph, ctx.dims, ctx.saved = graph, dims, saved
         return out
 
@@ -181,16 +218,16 @@ class _Propagate(torch.autograd.Function):
     def backward(ctx, d_out):
         d0, dws = propagate_backward(ctx.graph.transpose(), d_out.contiguous(), ctx.saved, ctx.dims)
         ctx.saved = None
-        return (None, None, d0, *_mat_grads(dws))
+        return (None, None, None, None, d0, *_mat_grads(dws))
 
 
 class _PropagateBprLoss(torch.autograd.Function):
     """(table, mats) -> [mul_loss, l2reg_loss(propagated rows)] in one autograd node."""
 
     @staticmethod
-    def forward(ctx, graph, dims, n_user, n_item, trip, loss_kind, table, *mats):
+    def forward(ctx, graph, dims, n_user, n_item, trip, loss_kind, drops, seed, table, *mats):
         loss_rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user]) if RESTRICT_FORWARD else None
-        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims, loss_rows)
+        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims, loss_rows, drops, seed)
         B, dtot = trip.shape[0], out.shape[1]
         coef = torch.empty(B, dtype=torch.float32, device=out.device)
         partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=out.device)
@@ -216,7 +253,7 @@ class _PropagateBprLoss(torch.autograd.Function):
                                                   _lib.ptr(dU), _lib.ptr(dI), _lib.stream_ptr()), "bpr_bwd")
         d0, dws = propagate_backward(ctx.graph.transpose(), d_out, ctx.saved, ctx.dims)
         ctx.saved = ctx.out = None
-        return (None, None, None, None, None, None, d0, *_mat_grads(dws))
+        return (None, None, None, None, None, None, None, None, d0, *_mat_grads(dws))
 
 
 class NGCF(TableModel):
@@ -248,21 +285,34 @@ class NGCF(TableModel):
         self.reg = config["reg"]
         self.loss_func = config["mul_loss_func"]
         self.use_tag = config["use_tag"]
+        self.drop_seed = config.get("seed", 2020)
 
     def _mats(self):
         return [self.mat[f"{n}_{k}"] for k in range(self.num_layer) for n in ("W1", "b1", "W2", "b2")]
 
     def _fused_ok(self):
-        drop = self.training and any(p > 0 for p in self.message_drop_list[:self.num_layer])
         dl = self.dim_layer_list
         dims_ok = all(d in (16, 32, 64, 128) for d in dl) and all(a * b < 128 * 128 for a, b in zip(dl[:-1], dl[1:]))
-        return isinstance(self.norm_adj, Graph) and not drop and dims_ok
+        return isinstance(self.norm_adj, Graph) and dims_ok
+
+    def _drops(self):
+        """(per-layer drop rates, seed of this forward pass) when message dropout is active, else (None, 0): the counter-
+        based masks of the library (a function of seed, layer and element), a new seed per training-mode pass."""
+        drops = [float(p) for p in self.message_drop_list[:self.num_layer]]
+        if not (self.training and any(p > 0 for p in drops)):
+            return None, 0
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TagrecError("NGCF: message dropout draws a new seed on the host every step and cannot be captured in a "
+                                   "HIP graph")
+        self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+        return tuple(drops + [0.0] * (self.num_layer - len(drops))), (int(getattr(self, "drop_seed", 2020)) << 24) + self._drop_calls
 
     def _propagate(self):
         if self.agg_type != "bi_agg":
             raise NotImplementedError                         # ngcf.py:65-68
         if self._fused_ok():
-            return _Propagate.apply(self.norm_adj, tuple(self.dim_layer_list), self.table, *self._mats())
+            drops, seed = self._drops()
+            return _Propagate.apply(self.norm_adj, tuple(self.dim_layer_list), drops, seed, self.table, *self._mats())
         # operator-by-operator path (row folds, message dropout, odd widths): ngcf.py:73-90 as written
         x = self.table
         outs = [x]
@@ -281,8 +331,9 @@ class NGCF(TableModel):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
         nu, ni = self.num_list[0], self.num_list[1]
         if self.agg_type == "bi_agg" and self._fused_ok():
+            drops, seed = self._drops()
             res = _PropagateBprLoss.apply(self.norm_adj, tuple(self.dim_layer_list), nu, ni, batch_data,
-                                          H.loss_kind_id(self.loss_func), self.table, *self._mats())
+                                          H.loss_kind_id(self.loss_func), drops, seed, self.table, *self._mats())
             return res[0], self.reg * res[1]
         all_users, all_items = self.forward()[:2]
         loss, reg_loss = H.triplet_loss(all_users, all_items, all_users, all_items, batch_data, self.loss_func)

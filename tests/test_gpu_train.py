@@ -239,3 +239,48 @@ def test_fused_message_dropout_matches_masked_operator_form():
     m.table.grad = None
     sum(m.loss(b)).backward()
     assert torch.isfinite(m.table.grad).all() and float(m.table.grad.abs().sum()) > 0
+
+
+def test_ngcf_message_dropout_keeps_the_fused_kernels_and_matches_masked_operator_form():
+    """NGCF with message dropout (ngcf.py:85) stays on the MFMA dense kernels: the mask is the library's counter-based one,
+    applied between the dense kernel and the re-normalisation.  The same pass assembled from the unfused operators with
+    that mask applied explicitly must give the same output and the same gradients (table and W / b)."""
+    from tagrec_amd import ngcf as NG
+    ds = T.synth.make_cf_dataset(300, 250, 6000, seed=4)
+    p = [0.3, 0.0, 0.5]
+    cfg = T.get_config("ngcf", use_tag=False, dim_layer_list=[64, 32, 64], dim_latent=64, device=DEV, message_drop_list=p)
+    torch.manual_seed(0)
+    m = T.NGCF(ds, config=cfg)
+    m.train()
+    assert m._fused_ok()
+    n = m.table.shape[0]
+    out = m._propagate()
+    seed = (int(m.drop_seed) << 24) + m._drop_calls
+    w = torch.randn(out.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    (out * w).sum().backward()
+    got_out = out.detach().clone()
+    got = {k: v.grad.clone() for k, v in m.named_parameters()}
+    m.zero_grad()
+    x = m.table
+    outs = [x]
+    for k in range(3):
+        nei = H.split_mm(m.norm_adj, x)
+        s_ = torch.nn.functional.leaky_relu(torch.matmul(nei + x, m.mat[f"W1_{k}"] + m.mat[f"b1_{k}"]), 0.2)
+        b_ = torch.nn.functional.leaky_relu(torch.matmul(nei * x, m.mat[f"W2_{k}"] + m.mat[f"b2_{k}"]), 0.2)
+        x = s_ + b_
+        if p[k] > 0:
+            x = x * H.message_drop(torch.ones_like(x), p[k], NG._layer_seed(seed, k))
+        outs.append(H.normalize_rows(x))
+    ref = torch.cat(outs, dim=1)
+    (ref * w).sum().backward()
+    np.testing.assert_allclose(got_out.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    scale = max(float(v.grad.abs().max()) for v in m.parameters())
+    for k, v in m.named_parameters():
+        np.testing.assert_allclose(got[k].cpu().numpy(), v.grad.cpu().numpy(), rtol=2e-3, atol=2e-5 * scale, err_msg=k)
+    # the loss path (restricted top layers, batch rows compact) with dropout: finite, differentiable, a new mask per pass
+    b = torch.from_numpy(T.synth.sample_bpr_epoch(ds, 0)[:16]).to(DEV)
+    m.zero_grad()
+    l1 = m.loss(b)
+    sum(l1).backward()
+    assert all(torch.isfinite(v.grad).all() for v in m.parameters()) and float(m.table.grad.abs().sum()) > 0
+    assert float(sum(m.loss(b))) != float(sum(l1))
