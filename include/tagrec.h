@@ -63,6 +63,15 @@ int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int6
  * scanning again (no synchronisation).  `like` must outlive the new handle. */
 int tagrec_graph_create_like(tagrec_graph** out, const tagrec_graph* like, int64_t n_cols, const int32_t* colidx,
                              const float* vals);
+/* The same two constructors on a CALLER-PROVIDED workspace of tagrec_graph_workspace(nnz) bytes (256-byte aligned, must
+ * outlive the handle): nothing is allocated or freed on the device -- for matrices built and dropped inside a training
+ * step (the inverted neighbour tables of the TGCN attention backward, tgcn.py:20-37).  create_ws still reads two counters
+ * back (one stream synchronisation); create_like_ws is asynchronous. */
+int64_t tagrec_graph_workspace(int64_t nnz);
+int tagrec_graph_create_ws(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr,
+                           const int32_t* colidx, const float* vals, void* workspace, int64_t workspace_bytes, void* stream);
+int tagrec_graph_create_like_ws(tagrec_graph** out, const tagrec_graph* like, int64_t n_cols, const int32_t* colidx,
+                                const float* vals, void* workspace, int64_t workspace_bytes);
 int tagrec_graph_destroy(tagrec_graph* g);
 int tagrec_graph_info(const tagrec_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
                       int64_t* n_long_rows, int64_t* n_chunks);

@@ -26,6 +26,10 @@ _SIGNATURES = {
     "tagrec_device_info": [POINTER(c_int), POINTER(c_int), c_char_p, c_int],
     "tagrec_graph_create": [POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_graph_create_like": [POINTER(c_void_p), c_void_p, c_int64, c_void_p, c_void_p],
+    "tagrec_graph_workspace": [c_int64],
+    "tagrec_graph_create_ws": [POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                               c_void_p],
+    "tagrec_graph_create_like_ws": [POINTER(c_void_p), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64],
     "tagrec_graph_destroy": [c_void_p],
     "tagrec_graph_info": [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
                           POINTER(c_int64)],

@@ -16,7 +16,9 @@ struct tagrec_graph {
   int2* chunk_desc;
   float* slab;                // n_chunks x kSlabWidth partial sums, allocated with the handle (scratch of the launch in
   size_t slab_floats;         // flight: one stream per handle)
-  bool owns_long;             // false: long_rows / long_base / chunk_desc belong to the graph this one was created like
+  bool owns_long;             // false: long_rows / long_base / chunk_desc belong to the graph this one was created like,
+                              // or live in a caller-provided workspace
+  bool owns_slab;             // false: the slab lives in a caller-provided workspace
 };
 
 namespace tagrec {

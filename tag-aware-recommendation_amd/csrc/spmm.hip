@@ -503,7 +503,7 @@ extern "C" int tagrec_graph_create(tagrec_graph** out, int64_t n_rows, int64_t n
   hipStream_t s = static_cast<hipStream_t>(stream);
   tagrec_graph* g = new (std::nothrow) tagrec_graph();
   if (!g) return fail(TAGREC_E_NOMEM, "graph_create: host allocation failed");
-  *g = tagrec_graph{n_rows, n_cols, nnz, rowptr, colidx, vals, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, true};
+  *g = tagrec_graph{n_rows, n_cols, nnz, rowptr, colidx, vals, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, true, true};
   if (n_rows > 0) {
     unsigned long long* counters = nullptr;
     unsigned long long host[4] = {0, 0, 0, 0};
@@ -555,11 +555,109 @@ extern "C" int tagrec_graph_create_like(tagrec_graph** out, const tagrec_graph* 
   g->slab = nullptr;
   g->slab_floats = 0;
   g->owns_long = false;
+  g->owns_slab = true;
   if (g->n_chunks > 0) {   // its own slab: the two matrices may be multiplied back to back on one stream
     hipError_t err = hipMalloc(&g->slab, sizeof(float) * kSlabWidth * g->n_chunks);
     if (err != hipSuccess) { delete g; return fail(TAGREC_E_HIP, std::string("graph_create_like: hipMalloc slab: ") + hipGetErrorString(err)); }
     g->slab_floats = static_cast<size_t>(kSlabWidth) * g->n_chunks;
   }
+  *out = g;
+  return TAGREC_OK;
+}
+
+// ---- handles on a caller-provided workspace: no hipMalloc / hipFree (short-lived matrices built inside a training step,
+// e.g. the inverted neighbour tables of the TGCN attention backward).  Upper bounds: a long row has > kLongRow entries, so
+// there are at most nnz / kLongRow of them, and a row of d entries has ceil(d / kChunk) <= d / kChunk + 1 chunks.
+namespace {
+struct WsLayout {
+  int64_t n_long_max, n_chunks_max;
+  size_t off_counters, off_long_rows, off_long_base, off_chunk_desc, off_slab, total;
+};
+WsLayout ws_layout(int64_t nnz) {
+  WsLayout w;
+  w.n_long_max = nnz / kLongRow + 1;
+  w.n_chunks_max = nnz / kChunk + w.n_long_max + 1;
+  auto up = [](size_t x) { return (x + 255) & ~static_cast<size_t>(255); };
+  size_t o = 0;
+  w.off_counters = o;   o = up(o + 4 * sizeof(unsigned long long));
+  w.off_long_rows = o;  o = up(o + sizeof(int32_t) * w.n_long_max);
+  w.off_long_base = o;  o = up(o + sizeof(int32_t) * w.n_long_max);
+  w.off_chunk_desc = o; o = up(o + sizeof(int2) * w.n_chunks_max);
+  w.off_slab = o;       o = up(o + sizeof(float) * kSlabWidth * w.n_chunks_max);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+extern "C" int64_t tagrec_graph_workspace(int64_t nnz) { return nnz < 0 ? 0 : static_cast<int64_t>(ws_layout(nnz).total); }
+
+extern "C" int tagrec_graph_create_ws(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr,
+                                      const int32_t* colidx, const float* vals, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
+  TAGREC_REQUIRE(out != nullptr && rowptr != nullptr, "graph_create_ws: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_rows < (1ll << 31) && n_cols < (1ll << 31), "graph_create_ws: bad size");
+  TAGREC_REQUIRE(nnz == 0 || (colidx != nullptr && vals != nullptr), "graph_create_ws: colidx/vals null with nnz > 0");
+  const WsLayout w = ws_layout(nnz);
+  TAGREC_REQUIRE(workspace != nullptr && workspace_bytes >= static_cast<int64_t>(w.total) &&
+                     (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
+                 "graph_create_ws: workspace smaller than tagrec_graph_workspace(nnz) or not 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  tagrec_graph* g = new (std::nothrow) tagrec_graph();
+  if (!g) return fail(TAGREC_E_NOMEM, "graph_create_ws: host allocation failed");
+  *g = tagrec_graph{n_rows, n_cols, nnz, rowptr, colidx, vals, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, false, false};
+  if (n_rows > 0) {
+    char* base = static_cast<char*>(workspace);
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(base + w.off_counters);
+    unsigned long long host[4] = {0, 0, 0, 0};
+    auto bail = [&](const char* what, hipError_t e2) {
+      delete g;
+      return fail(TAGREC_E_HIP, std::string("graph_create_ws: ") + what + ": " + hipGetErrorString(e2));
+    };
+    hipError_t err;
+    const int threads = 256;
+    const unsigned blocks = static_cast<unsigned>((n_rows + threads - 1) / threads);
+    if ((err = hipMemsetAsync(counters, 0, sizeof(host), s)) != hipSuccess) return bail("memset", err);
+    count_long_kernel<<<blocks, threads, 0, s>>>(rowptr, n_rows, counters);
+    if ((err = hipGetLastError()) != hipSuccess) return bail("count_long launch", err);
+    g->long_rows = reinterpret_cast<int32_t*>(base + w.off_long_rows);
+    g->long_base = reinterpret_cast<int32_t*>(base + w.off_long_base);
+    g->chunk_desc = reinterpret_cast<int2*>(base + w.off_chunk_desc);
+    g->slab = reinterpret_cast<float*>(base + w.off_slab);
+    // the fill runs unconditionally (it writes nothing when no row is long), so one read-back serves both kernels
+    fill_long_kernel<<<blocks, threads, 0, s>>>(rowptr, n_rows, counters, g->long_rows, g->long_base, g->chunk_desc);
+    if ((err = hipGetLastError()) != hipSuccess) return bail("fill_long launch", err);
+    if ((err = hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail("memcpy", err);
+    if ((err = hipStreamSynchronize(s)) != hipSuccess) return bail("sync", err);
+    g->n_long = static_cast<int64_t>(host[0]);
+    g->n_chunks = static_cast<int64_t>(host[1]);
+    if (g->n_long > w.n_long_max || g->n_chunks > w.n_chunks_max) {
+      delete g;
+      return fail(TAGREC_E_INVALID, "graph_create_ws: row pointer inconsistent with nnz (more long rows than nnz allows)");
+    }
+    g->slab_floats = static_cast<size_t>(kSlabWidth) * g->n_chunks;
+  }
+  *out = g;
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_graph_create_like_ws(tagrec_graph** out, const tagrec_graph* like, int64_t n_cols, const int32_t* colidx,
+                                           const float* vals, void* workspace, int64_t workspace_bytes) {
+  TAGREC_REQUIRE(out != nullptr && like != nullptr, "graph_create_like_ws: null handle");
+  TAGREC_REQUIRE(n_cols >= 0 && n_cols < (1ll << 31), "graph_create_like_ws: node ids must fit int32");
+  TAGREC_REQUIRE(like->nnz == 0 || (colidx != nullptr && vals != nullptr), "graph_create_like_ws: colidx/vals null with nnz > 0");
+  const WsLayout w = ws_layout(like->nnz);
+  TAGREC_REQUIRE(workspace != nullptr && workspace_bytes >= static_cast<int64_t>(w.total) &&
+                     (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
+                 "graph_create_like_ws: workspace smaller than tagrec_graph_workspace(nnz) or not 256-byte aligned");
+  tagrec_graph* g = new (std::nothrow) tagrec_graph(*like);
+  if (!g) return fail(TAGREC_E_NOMEM, "graph_create_like_ws: host allocation failed");
+  g->n_cols = n_cols;
+  g->col = colidx;
+  g->val = vals;
+  g->owns_long = false;
+  g->owns_slab = false;
+  g->slab = reinterpret_cast<float*>(static_cast<char*>(workspace) + w.off_slab);   // only the slab part is used
+  g->slab_floats = static_cast<size_t>(kSlabWidth) * g->n_chunks;
   *out = g;
   return TAGREC_OK;
 }
@@ -571,7 +669,7 @@ extern "C" int tagrec_graph_destroy(tagrec_graph* g) {
     (void)hipFree(g->long_base);
     (void)hipFree(g->chunk_desc);
   }
-  (void)hipFree(g->slab);
+  if (g->owns_slab) (void)hipFree(g->slab);
   delete g;
   return TAGREC_OK;
 }

@@ -196,7 +196,9 @@ class Graph:
     """Device CSR + the library handle built on it.  Owns the three tensors (the
     library only borrows them) and, lazily, the transposed graph for backward."""
 
-    def __init__(self, rowptr, col, val, shape, symmetric=False):
+    def __init__(self, rowptr, col, val, shape, symmetric=False, workspace=False):
+        """workspace=True: the handle's device metadata (long-row work list, partial-sum slab) lives in a torch tensor
+        owned by this object instead of hipMalloc'ed memory -- for matrices created and dropped inside a training step."""
         self.rowptr = _lib.require_gpu_tensor(rowptr, torch.int64, "rowptr")
         self.col = _lib.require_gpu_tensor(col, torch.int32, "col")
         self.val = _lib.require_gpu_tensor(val, torch.float32, "val")
@@ -208,10 +210,20 @@ class Graph:
         self.timing = None            # set to {} to record (start, end) HIP events per kernel entry point
         self._h = _lib.c_void_p()
         lib = _lib.load()
+        self._ws = None
         with torch.cuda.device(self.val.device):
-            _lib.check(lib.tagrec_graph_create(_lib.ctypes.byref(self._h), self.shape[0], self.shape[1], col.numel(),
-                                               _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()),
-                       "graph_create")
+            if workspace:
+                nb = lib.tagrec_graph_workspace(col.numel())
+                self._ws = torch.empty(nb + 256, dtype=torch.uint8, device=self.val.device)
+                off = (-self._ws.data_ptr()) % 256
+                self._ws_ptr = self._ws.data_ptr() + off
+                _lib.check(lib.tagrec_graph_create_ws(_lib.ctypes.byref(self._h), self.shape[0], self.shape[1], col.numel(),
+                                                      _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.c_void_p(self._ws_ptr),
+                                                      nb, _lib.stream_ptr()), "graph_create_ws")
+            else:
+                _lib.check(lib.tagrec_graph_create(_lib.ctypes.byref(self._h), self.shape[0], self.shape[1], col.numel(),
+                                                   _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()),
+                           "graph_create")
 
     def like(self, col, val, n_cols):
         """A second matrix over this graph's row pointer with its own columns / values; shares the long-row work list
@@ -225,8 +237,17 @@ class Graph:
         g.shape = (self.shape[0], int(n_cols))
         g.symmetric, g._T, g.timing, g._parent = False, None, None, self
         g._h = _lib.c_void_p()
-        _lib.check(_lib.load().tagrec_graph_create_like(_lib.ctypes.byref(g._h), self._h, g.shape[1], _lib.ptr(col),
-                                                        _lib.ptr(val)), "graph_create_like")
+        g._ws = None
+        lib = _lib.load()
+        if self._ws is not None:                       # a workspace-backed graph begets workspace-backed ones
+            nb = lib.tagrec_graph_workspace(self.col.numel())
+            g._ws = torch.empty(nb + 256, dtype=torch.uint8, device=self.val.device)
+            g._ws_ptr = g._ws.data_ptr() + (-g._ws.data_ptr()) % 256
+            _lib.check(lib.tagrec_graph_create_like_ws(_lib.ctypes.byref(g._h), self._h, g.shape[1], _lib.ptr(col), _lib.ptr(val),
+                                                       _lib.c_void_p(g._ws_ptr), nb), "graph_create_like_ws")
+            return g
+        _lib.check(lib.tagrec_graph_create_like(_lib.ctypes.byref(g._h), self._h, g.shape[1], _lib.ptr(col),
+                                                _lib.ptr(val)), "graph_create_like")
         return g
 
     @classmethod

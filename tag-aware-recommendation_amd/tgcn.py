@@ -90,8 +90,9 @@ def _pull_compact(idxc, attnc, doc, dh, n_dst):
     key = torch.where(flat > 0, flat - 1, n_dst)
     skey, order = torch.sort(key, stable=True)
     rowptr = torch.searchsorted(skey, torch.arange(n_dst + 1, dtype=skey.dtype, device=skey.device))
+    # short-lived handles: their device metadata lives in torch-allocated workspaces (no hipMalloc / hipFree per call)
     G = Graph(rowptr, torch.div(order, k, rounding_mode="floor").to(torch.int32), attnc.flatten().index_select(0, order),
-              (n_dst, nc))
+              (n_dst, nc), workspace=True)
     S = G.like(order.to(torch.int32), torch.ones_like(G.val), nc * k)
     return S.spmm(dh), G.spmm(doc)
 

@@ -122,6 +122,30 @@ def test_graph_like_shares_the_long_row_list():
     assert torch.equal(twin.spmm(X), fresh.spmm(X))
 
 
+def test_workspace_backed_graph_handles():
+    """`Graph(..., workspace=True)` and its `like()` twins keep their device metadata (long-row work list, partial-sum slab)
+    in a torch tensor instead of hipMalloc'ed memory -- the short-lived matrices of the TGCN attention backward -- and must
+    give bit-identical products, long rows and every vector width included; an empty matrix works too."""
+    rng = np.random.RandomState(3)
+    csr = _star_graph(6000, 5000, rng)
+    ref = _graph(csr)
+    g = T.Graph(ref.rowptr, ref.col, ref.val, ref.shape, workspace=True)
+    assert g.info() == ref.info() and g.info()["n_long_rows"] == 2
+    gen = torch.Generator().manual_seed(5)
+    for D in (8, 64, 256):
+        X = torch.randn(ref.shape[1], D, generator=gen).to(DEV)
+        assert torch.equal(g.spmm(X), ref.spmm(X))
+    col2 = torch.randint(0, 333, (ref.nnz,), generator=gen, dtype=torch.int32).to(DEV)
+    val2 = torch.randn(ref.nnz, generator=gen).to(DEV)
+    twin, fresh = g.like(col2, val2, 333), T.Graph(ref.rowptr, col2, val2, (6000, 333))
+    X = torch.randn(333, 32, generator=gen).to(DEV)
+    assert torch.equal(twin.spmm(X), fresh.spmm(X)) and torch.equal(g.spmm(torch.ones(ref.shape[1], 8, device=DEV)),
+                                                                    ref.spmm(torch.ones(ref.shape[1], 8, device=DEV)))
+    empty = T.Graph(torch.zeros(5, dtype=torch.int64, device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV),
+                    torch.zeros(0, device=DEV), (4, 7), workspace=True)
+    assert float(empty.spmm(torch.ones(7, 8, device=DEV)).abs().sum()) == 0.0
+
+
 def test_spmm_rejects_bad_arguments():
     rng = np.random.RandomState(1)
     csr = oadj.coo_to_csr(rng.randint(0, 100, 500), rng.randint(0, 100, 500), rng.rand(500), (100, 100))
