@@ -726,6 +726,290 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
   for (int i = threadIdx.x; i < NSM; i += kFuseThreads) o[i] = sh[i];
 }
 
+// ---- backward, data part, TWO WAVES PER SIMD (D = 128) ------------------------------------------------------------
+// The kernel above keeps the whole e / de tile of a subtile in registers (2 x 3 x D/4 = 192 at D = 128) and lands at
+// 512 registers per wave: one wave per SIMD, nothing hides the LDS / MFMA / VALU latencies of the main loop (MFMA pipe
+// 41 % busy).  Here a tile is processed in two passes over HALVES of the feature blocks, so that only 2 x 3 x D/8 = 96
+// accumulator / operand registers are live in the main loop and two waves fit a SIMD:
+//   A  type attention (full vectors, transient) -> bw; vector-level pre-activations -> dpv, yvec, dfeat
+//   B  for half h: e_h = bw t_h; main (c, b) loop over the b-blocks of the half (same LDS ring of Wf rows, the stream now
+//      runs half 0 of every filter, then half 1); vector-level contribution; partial softmax dots; de_h -> dT (scratch)
+//   C  type attention again (192 MFMAs against the main loop's 8192) for the pre-activations -> dS, dq, dp
+//   D  dt = bw de + U dS, reading de back from dT
+template <int D, int DOUT, int A>
+__global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
+    const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, int64_t n,
+    const float* __restrict__ U, const float* __restrict__ qv, const float* __restrict__ pv,
+    const float* __restrict__ wb, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ w3, const float* __restrict__ Wf, const float* __restrict__ outv,
+    const float* __restrict__ dOut, float* __restrict__ dT0, float* __restrict__ dT1, float* __restrict__ dT2,
+    float* __restrict__ yvec, float* __restrict__ dfeat, float* __restrict__ dS, float* __restrict__ part) {
+  constexpr int DS = D / 4, HS = DS / 2, OS = DOUT / 4, IB = D / 16, HB = IB / 2, AB = A / 16, AS = A / 4;
+  constexpr int NSM = 3 * kBitC + 2 * A;             // dwb | dq | dp
+  __shared__ float sh[NSM];
+  constexpr int NB = 2;
+  constexpr int RP = 256 / DOUT, PPW = (NB * 16 / RP) / 4, CHUNK = NB * 16 * DOUT * 4;
+  constexpr int NBUF = 3, CPH = HB / NB, NCH = 2 * kBitC * CPH;   // chunks per (filter, half); chunks per tile group
+  static_assert(HB % NB == 0 && CPH >= 1 && NCH >= 4, "tgcn_fuse_bwd2: unsupported shape");
+  __shared__ __attribute__((aligned(1024))) char wbuf[NBUF][CHUNK];
+  for (int i = threadIdx.x; i < NSM; i += kFuseThreads) sh[i] = 0.f;
+  __syncthreads();
+  float* sh_wb = sh;
+  float* sh_q = sh + 3 * kBitC;
+  float* sh_p = sh_q + A;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (n + 15) / 16;
+  const float* Tj[3] = {T0, T1, T2};
+  float* dTj[3] = {dT0, dT1, dT2};
+  auto swz = [](int row) {
+    const int x = ((row >> 3) ^ (row >> 2)) & 1;
+    return DOUT == 128 ? ((row & 0xB) | (x << 2)) : ((row & 0x7) | (x << 3));
+  };
+  const int lanes_per_row = DOUT / 4;
+  const int dma_row = lane / lanes_per_row, dma_unit = lane % lanes_per_row;
+  const int drow = (r >> 2) * DS + (r & 3);
+  float q_acc[AS], p_acc[AS];
+#pragma unroll
+  for (int i = 0; i < AS; ++i) { q_acc[i] = 0.f; p_acc[i] = 0.f; }
+  const int64_t it_first = static_cast<int64_t>(blockIdx.x), it_step = static_cast<int64_t>(gridDim.x);
+  const int64_t it_end = (n_tiles + 3) / 4;
+  auto issue = [&](int j, int buf) {                     // chunk j of the tile group's stream
+    const int h = j / (kBitC * CPH), rem = j % (kBitC * CPH);
+    const int c = rem / CPH, b = h * HB + (rem % CPH) * NB;
+#pragma unroll
+    for (int jj = 0; jj < PPW; ++jj) {
+      const int p = wave * PPW + jj;
+      const int lrow = p * RP + dma_row;
+      const int sub = lrow >> 4, i = lrow & 15;
+      const int u = dma_unit ^ swz(i);
+      const float* src = Wf + (static_cast<int64_t>(c) * D + (i >> 2) * DS + (i & 3) + 4 * (b + sub)) * DOUT + u * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)&wbuf[buf][p * 1024], 16, 0, 0);
+    }
+  };
+  int cur = 0;
+  if (it_first < it_end) { issue(0, 0); issue(1, 1); }
+  for (int64_t it = it_first; it < it_end; it += it_step) {
+    const int64_t tile = it * 4 + wave;
+    const bool has_next = it + it_step < it_end;
+    U = fresh(U); qv = fresh(qv); pv = fresh(pv); wb = fresh(wb); w1 = fresh(w1); w2 = fresh(w2); w3 = fresh(w3);
+    Wf = fresh(Wf);
+    const int64_t node = tile * 16 + r;
+    const bool ok = node < n;
+    float g[OS];
+    {
+      float o[OS];
+      load_seg<OS>(dOut + node * DOUT + q * OS, ok, g);
+      load_seg<OS>(outv + node * DOUT + q * OS, ok, o);
+#pragma unroll
+      for (int i = 0; i < OS; ++i) g[i] = o[i] > 0.f ? g[i] : 0.f;
+    }
+    // ---- A: attention weights and the vector-level features (full vectors, transient)
+    float bw[3];
+    f32x4 dpv[6];
+    {
+      float e3[3][DS];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) load_seg<DS>(Tj[j] + node * D + q * DS, ok, e3[j]);
+      f32x4 sc[3][AB];
+      type_attention<D, A>(e3, U, qv, pv, r, q, sc, bw);
+      f32x4 pre[6];
+      vector_conv<D>(e3, w1, w2, w3, r, q, pre);
+#pragma unroll
+      for (int gi = 0; gi < 6; ++gi) {
+        const int f = vec_feature(gi, r & 7);
+        float a[OS];
+        load_run<OS>(Wf + (static_cast<int64_t>(kBitC) * D + f) * DOUT + q * OS, a);
+        f32x4 dy = zero4();
+#pragma unroll
+        for (int t = 0; t < OS; ++t) dy = __builtin_amdgcn_mfma_f32_16x16x4f32(r < kVecC ? a[t] : 0.f, g[t], dy, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const bool live = q < 2;
+          const float y = live ? fmaxf(pre[gi][v], 0.f) : 0.f;
+          dpv[gi][v] = (live && pre[gi][v] > 0.f) ? dy[v] : 0.f;
+          if (ok && live) {
+            const int ff = vec_feature(gi, 4 * q + v);
+            yvec[node * (6 * kVecC) + ff] = y;
+            dfeat[node * (6 * kVecC) + ff] = dpv[gi][v];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- B: the two halves of the feature blocks
+    float db[3] = {0.f, 0.f, 0.f};
+    for (int h = 0; h < 2; ++h) {
+      float e3h[3][HS], de3h[3][HS];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        load_seg<HS>(Tj[j] + node * D + q * DS + h * HS, ok, e3h[j]);
+#pragma unroll
+        for (int e = 0; e < HS; ++e) { e3h[j][e] *= bw[j]; de3h[j][e] = 0.f; }
+      }
+      for (int c = 0; c < kBitC; ++c) {
+        const float c0 = wb[c * 3], c1 = wb[c * 3 + 1], c2 = wb[c * 3 + 2];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int bl = 0; bl < HB; ++bl) {
+          if (bl % NB == 0) {
+            const int j = (h * kBitC + c) * CPH + bl / NB;      // chunk number inside the tile group
+            if (j + 1 < NCH || has_next) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int j2 = j + 2;
+            const bool wrap = j2 >= NCH;
+            if (wrap) j2 -= NCH;
+            if (!wrap || has_next) issue(j2, cur >= 1 ? cur - 1 : NBUF - 1);
+          }
+          f32x4 dy = zero4(), dy1 = zero4();
+          const char* rowp = &wbuf[cur][((bl % NB) * 16 + r) * DOUT * 4];
+          const int sw = swz(r);
+          auto piece = [&](int t4) { return *reinterpret_cast<const float4*>(rowp + (((q * (OS / 4) + t4) ^ sw) << 4)); };
+          float4 w0 = piece(0), w1_ = piece(1 < OS / 4 ? 1 : 0);
+#pragma unroll
+          for (int t4 = 0; t4 < OS / 4; ++t4) {
+            const float4 w2_ = piece(t4 + 2 < OS / 4 ? t4 + 2 : t4);
+            const int t = 4 * t4;
+            dy = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, g[t], dy, 0, 0, 0);
+            dy1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, g[t + 1], dy1, 0, 0, 0);
+            dy = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, g[t + 2], dy, 0, 0, 0);
+            dy1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, g[t + 3], dy1, 0, 0, 0);
+            w0 = w1_; w1_ = w2_;
+          }
+          dy += dy1;
+          if (bl % NB == NB - 1) cur = cur == NBUF - 1 ? 0 : cur + 1;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int e = 4 * bl + v;
+            const float pre = fmaf(c0, e3h[0][e], fmaf(c1, e3h[1][e], c2 * e3h[2][e]));
+            const float dp_ = pre > 0.f ? dy[v] : 0.f;
+            de3h[0][e] = fmaf(c0, dp_, de3h[0][e]);
+            de3h[1][e] = fmaf(c1, dp_, de3h[1][e]);
+            de3h[2][e] = fmaf(c2, dp_, de3h[2][e]);
+            a0 = fmaf(dp_, e3h[0][e], a0);
+            a1 = fmaf(dp_, e3h[1][e], a1);
+            a2 = fmaf(dp_, e3h[2][e], a2);
+          }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+        if (lane == 0) { atomicAdd(&sh_wb[c * 3], a0); atomicAdd(&sh_wb[c * 3 + 1], a1); atomicAdd(&sh_wb[c * 3 + 2], a2); }
+      }
+      // vector-level contribution to the half: de_h[d] += sum_c w[c][a][d] dpre[c]
+#pragma unroll
+      for (int bl = 0; bl < HB; ++bl) {
+        const int d = drow + 4 * (h * HB + bl);
+        f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = 4 * (q & 1) + v;
+          const float z = q < 2 ? 1.f : 0.f;
+          const float k1 = z * w1[c * D + d];
+          const float k20 = z * w2[(c * 2 + 0) * D + d], k21 = z * w2[(c * 2 + 1) * D + d];
+          const float k30 = z * w3[(c * 3 + 0) * D + d], k31 = z * w3[(c * 3 + 1) * D + d], k32 = z * w3[(c * 3 + 2) * D + d];
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, dpv[0][v], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, dpv[1][v], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, dpv[2][v], acc2, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k20, dpv[3][v], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k21, dpv[3][v], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k20, dpv[4][v], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(k21, dpv[4][v], acc2, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k30, dpv[5][v], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k31, dpv[5][v], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(k32, dpv[5][v], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          de3h[0][4 * bl + v] += acc0[v];
+          de3h[1][4 * bl + v] += acc1[v];
+          de3h[2][4 * bl + v] += acc2[v];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the half's share of db_j = de_j . t_j, and de_h out to dT (read back in D)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float th[HS];
+        load_seg<HS>(Tj[j] + node * D + q * DS + h * HS, ok, th);
+        float s_ = 0.f;
+#pragma unroll
+        for (int e = 0; e < HS; ++e) s_ = fmaf(de3h[j][e], th[e], s_);
+        db[j] += s_;
+        if (ok) {
+          float* dst = dTj[j] + node * D + q * DS + h * HS;
+#pragma unroll
+          for (int e = 0; e < HS; e += 4)
+            *reinterpret_cast<float4*>(dst + e) = make_float4(de3h[j][e], de3h[j][e + 1], de3h[j][e + 2], de3h[j][e + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) db[j] = quad_sum(db[j]);
+    // ---- C: through the type-level softmax (pre-activations recomputed)
+    float dsv[3][AS];
+    {
+      float t[3][DS];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) load_seg<DS>(Tj[j] + node * D + q * DS, ok, t[j]);
+      f32x4 sc[3][AB];
+      float bw2[3];
+      type_attention<D, A>(t, U, qv, pv, r, q, sc, bw2);
+      const float mix = bw[0] * db[0] + bw[1] * db[1] + bw[2] * db[2];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float ds = bw[j] * (db[j] - mix);
+#pragma unroll
+        for (int ab = 0; ab < AB; ++ab)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int t_ = v * AB + ab;
+            const float hh = sc[j][ab][v];
+            const float x = hh > 0.f ? ds * pv[q * AS + t_] : 0.f;
+            dsv[j][t_] = x;
+            q_acc[t_] += x;
+            p_acc[t_] = fmaf(ds, fmaxf(hh, 0.f), p_acc[t_]);
+          }
+        if (ok) {
+          float* dst = dS + node * (3 * A) + j * A + q * AS;
+#pragma unroll
+          for (int t_ = 0; t_ < AS; t_ += 4)
+            *reinterpret_cast<float4*>(dst + t_) = make_float4(dsv[j][t_], dsv[j][t_ + 1], dsv[j][t_ + 2], dsv[j][t_ + 3]);
+        }
+      }
+    }
+    // ---- D: dt_j = bw_j de_j + U dS_j  (de_j read back from dT: written by this lane above)
+#pragma unroll
+    for (int b = 0; b < IB; ++b) {
+      float ua[AS];
+      load_run<AS>(U + static_cast<int64_t>(drow + 4 * b) * A + q * AS, ua);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int t_ = 0; t_ < AS; ++t_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[t_], dsv[j][t_], acc, 0, 0, 0);
+        if (ok) {
+          float4* p4 = reinterpret_cast<float4*>(dTj[j] + node * D + q * DS + 4 * b);
+          const float4 de = *p4;
+          *p4 = make_float4(fmaf(bw[j], de.x, acc[0]), fmaf(bw[j], de.y, acc[1]), fmaf(bw[j], de.z, acc[2]), fmaf(bw[j], de.w, acc[3]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < AS; ++i) {
+    float a = q_acc[i], b = p_acc[i];
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+    b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4); b += __shfl_xor(b, 8);
+    if (r == 0) { atomicAdd(&sh_q[q * AS + i], a); atomicAdd(&sh_p[q * AS + i], b); }
+  }
+  __syncthreads();
+  float* o = part + static_cast<int64_t>(blockIdx.x) * NSM;
+  for (int i = threadIdx.x; i < NSM; i += kFuseThreads) o[i] = sh[i];
+}
+
 __global__ void fuse_fold_kernel(const float* __restrict__ part, int n_parts, int elems, float* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= elems) return;
@@ -748,8 +1032,14 @@ int launch_fuse_bwd(const float* T0, const float* T1, const float* T2, int64_t n
   int64_t blocks = (tiles + 3) / 4;
   if (blocks > kFuseBwdBlocks) blocks = kFuseBwdBlocks;
   constexpr bool kLds = (D == 64 || D == 128) && (DOUT == 64 || DOUT == 128);
-  tgcn_fuse_bwd_kernel<D, DOUT, A, kLds><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
-      T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, outv, dOut, dT0, dT1, dT2, yvec, dfeat, dS, ws);
+  if constexpr (D == 128 && kLds) {
+    // two waves per SIMD: the tile's feature blocks in two passes (see tgcn_fuse_bwd2_kernel)
+    tgcn_fuse_bwd2_kernel<D, DOUT, A><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
+        T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, outv, dOut, dT0, dT1, dT2, yvec, dfeat, dS, ws);
+  } else {
+    tgcn_fuse_bwd_kernel<D, DOUT, A, kLds><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
+        T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, outv, dOut, dT0, dT1, dT2, yvec, dfeat, dS, ws);
+  }
   TAGREC_LAUNCH_CHECK();
   fuse_fold_kernel<<<(NSM + 255) / 256, 256, 0, s>>>(ws, static_cast<int>(blocks), NSM, small);
   TAGREC_LAUNCH_CHECK();
