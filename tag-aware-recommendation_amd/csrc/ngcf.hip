@@ -14,6 +14,11 @@
 //   backward dA  dA^T = W'   . dP^T     A-operand W'[i][k]  from LDS (transposed copy, stride Din+4)
 //   backward dW  dW'  = A^T  . dP       both operands straight from global (rows on the k axis)
 // HBM-bound (about 2 GB per layer and pass at C3); the MFMA work is ~0.2 ms per product at C3.
+//
+// 128 -> 128 layers: both LDS copies of both matrices would take 270 KB, and the weight-gradient accumulators of both
+// matrices 512 registers.  That shape runs the backward and the weight gradient ONE MATRIX PER LAUNCH (template MAT):
+// the k-major and the transposed copy of one matrix fit (135 KB), pass 1 writes dN = dX_direct = dA1, pass 2 adds
+// dA2 * X and dA2 * N to them; the forward keeps both k-major copies (135 KB), one block per CU.
 #include "common.h"
 
 namespace tagrec {
@@ -28,6 +33,8 @@ __device__ __forceinline__ float lrelu_grad(float x) { return x > 0.f ? 1.f : kS
 
 template <int DIN, int DOUT>
 struct NgcfShape {
+  static constexpr bool kBig = DIN * DOUT >= 128 * 128;      // one matrix per launch in the backward kernels
+  static constexpr int kOcc = kBig ? 1 : 2;                  // blocks per CU the register budget is set for
   static constexpr int IB = DIN / 16, MB = DOUT / 16;
   static constexpr int LDW = DOUT + 4;   // k-major W' rows: lanes run over the Dout index
   static constexpr int LDT = DIN + 4;    // transposed copy: lanes run over the Din index
@@ -52,6 +59,39 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ W1, const
     }
   }
   __syncthreads();
+}
+
+// one matrix: k-major copy at lds, transposed copy behind it
+template <int DIN, int DOUT>
+__device__ __forceinline__ void load_weights_one(const float* __restrict__ W, float* lds) {
+  using S = NgcfShape<DIN, DOUT>;
+  float* w = lds;
+  float* t = w + DIN * S::LDW;
+  for (int e = threadIdx.x; e < DIN * DOUT; e += kNgcfThreads) {
+    const int k = e / DOUT, m = e % DOUT;
+    const float a = W[e];
+    w[k * S::LDW + m] = a;
+    t[m * S::LDT + k] = a;
+  }
+  __syncthreads();
+}
+
+template <int DIN, int DOUT>
+__device__ __forceinline__ void product_one(const float* w, const f32x4 (&a)[DIN / 16], f32x4 (&p)[DOUT / 16], int lane) {
+  using S = NgcfShape<DIN, DOUT>;
+  const int m = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int mb = 0; mb < S::MB; ++mb) p[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ib = 0; ib < S::IB; ++ib) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = ib * 16 + q * 4 + v;
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb)
+        p[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k * S::LDW + mb * 16 + m], a[ib][v], p[mb], 0, 0, 0);
+    }
+  }
 }
 
 // P1^T, P2^T for the wave's 16 rows; a1/a2 are the lane's operand registers (see header comment)
@@ -95,7 +135,7 @@ __device__ __forceinline__ void load_inputs(const float* __restrict__ Nn, const 
 
 // ---- forward -----------------------------------------------------------------------------------
 template <int DIN, int DOUT>
-__global__ __launch_bounds__(kNgcfThreads, 2) void ngcf_fwd_kernel(const float* __restrict__ Nn, const float* __restrict__ X,
+__global__ __launch_bounds__(kNgcfThreads, (NgcfShape<DIN, DOUT>::kOcc)) void ngcf_fwd_kernel(const float* __restrict__ Nn, const float* __restrict__ X,
                                                                 const float* __restrict__ W1, const float* __restrict__ W2,
                                                                 int64_t n_rows, float* __restrict__ Xp,
                                                                 float* __restrict__ inv_norm, float* __restrict__ Z,
@@ -237,6 +277,134 @@ __global__ __launch_bounds__(kNgcfThreads) void ngcf_bwd_kernel(const float* __r
   }
 }
 
+// ---- backward, activation part, ONE matrix per launch (128 -> 128: see the header) ----------------------------------
+// MAT = 1: dP1, dN = dX_direct = dA1.   MAT = 2: dP2, dN += dA2 * X, dX_direct += dA2 * N (read-modify-write).
+template <int DIN, int DOUT, bool NORM, int MAT>
+__global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_bwd_one_kernel(const float* __restrict__ dXp, NormGrad ng,
+                                                                    const float* __restrict__ Nn, const float* __restrict__ X,
+                                                                    const float* __restrict__ W, int64_t n_rows,
+                                                                    float* __restrict__ dNn, float* __restrict__ dXd,
+                                                                    float* __restrict__ dP) {
+  using S = NgcfShape<DIN, DOUT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  load_weights_one<DIN, DOUT>(W, lds);
+  const float* tw = lds + DIN * S::LDW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (n_rows + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row = tile * 64 + wave * 16 + r;
+    const bool ok = row < n_rows;
+    f32x4 nn[S::IB], x[S::IB], a[S::IB], p[S::MB];
+    load_inputs<DIN>(Nn, X, row, ok, q, nn, x);
+#pragma unroll
+    for (int ib = 0; ib < S::IB; ++ib) a[ib] = MAT == 1 ? nn[ib] + x[ib] : nn[ib] * x[ib];
+    product_one<DIN, DOUT>(lds, a, p, lane);                 // recompute this matrix's pre-activations
+    f32x4 gx[S::MB];
+#pragma unroll
+    for (int mb = 0; mb < S::MB; ++mb) {
+      gx[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok && dXp) gx[mb] = *reinterpret_cast<const f32x4*>(dXp + row * DOUT + mb * 16 + q * 4);
+    }
+    if constexpr (NORM) {
+      const float inv = ok ? ng.inv[row] : 0.f;
+      float dot = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb) {
+        if (ok) {
+          const f32x4 z = *reinterpret_cast<const f32x4*>(ng.Xp + row * DOUT + mb * 16 + q * 4) * inv;
+          const f32x4 dz = *reinterpret_cast<const f32x4*>(ng.dZ + row * ng.ldz + mb * 16 + q * 4);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) dot = fmaf(z[v], dz[v], dot);
+        }
+      }
+      dot += __shfl_xor(dot, 16);
+      dot += __shfl_xor(dot, 32);
+      if (inv >= 1e12f) dot = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb) {
+        if (ok) {                                              // (re-read: holding z and dz would cost 64 registers)
+          const f32x4 z = *reinterpret_cast<const f32x4*>(ng.Xp + row * DOUT + mb * 16 + q * 4) * inv;
+          const f32x4 dz = *reinterpret_cast<const f32x4*>(ng.dZ + row * ng.ldz + mb * 16 + q * 4);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) gx[mb][v] += inv * (dz[v] - z[v] * dot);
+        }
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < S::MB; ++mb) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) p[mb][v] = gx[mb][v] * lrelu_grad(p[mb][v]);
+      if (ok) *reinterpret_cast<f32x4*>(dP + row * DOUT + mb * 16 + q * 4) = p[mb];
+    }
+#pragma unroll
+    for (int ib = 0; ib < S::IB; ++ib) {
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mb = 0; mb < S::MB; ++mb) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int k = mb * 16 + q * 4 + v;
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(tw[k * S::LDT + ib * 16 + r], p[mb][v], d, 0, 0, 0);
+        }
+      }
+      if (ok) {
+        f32x4* pn = reinterpret_cast<f32x4*>(dNn + row * DIN + ib * 16 + q * 4);
+        f32x4* px = reinterpret_cast<f32x4*>(dXd + row * DIN + ib * 16 + q * 4);
+        if constexpr (MAT == 1) {
+          *pn = d;
+          *px = d;
+        } else {
+          *pn = *pn + d * x[ib];
+          *px = *px + d * nn[ib];
+        }
+      }
+    }
+  }
+}
+
+// weight gradient of ONE matrix (128 -> 128: 256 accumulator registers per matrix)
+template <int DIN, int DOUT, int MAT>
+__global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_wgrad_one_kernel(const float* __restrict__ Nn, const float* __restrict__ X,
+                                                                      const float* __restrict__ dP, int64_t n_rows,
+                                                                      int64_t steps_per_wave, float* __restrict__ slab) {
+  constexpr int IB = DIN / 16, JB = DOUT / 16;
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, q = lane >> 4;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * (kNgcfThreads / 64) + (threadIdx.x >> 6);
+  f32x4 acc[IB][JB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t s0 = w * steps_per_wave;
+  for (int64_t s = s0; s < s0 + steps_per_wave; ++s) {
+    const int64_t row = s * 4 + q;
+    if (s * 4 >= n_rows) break;
+    const bool ok = row < n_rows;
+    float a[IB], b[JB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const float nv = ok ? Nn[row * DIN + i * 16 + m] : 0.f;
+      const float xv = ok ? X[row * DIN + i * 16 + m] : 0.f;
+      a[i] = MAT == 1 ? nv + xv : nv * xv;
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) b[j] = ok ? dP[row * DOUT + j * 16 + m] : 0.f;
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+      for (int j = 0; j < JB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  float* o = slab + w * 2 * DIN * DOUT + (MAT == 1 ? 0 : DIN * DOUT);
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) o[(i * 16 + q * 4 + v) * DOUT + j * 16 + m] = acc[i][j][v];
+}
+
 // ---- backward, weight part: dW1' = (N+X)^T dP1, dW2' = (N*X)^T dP2 -------------------------------
 // Each wave owns a contiguous strip of rows and a full set of DIN x DOUT accumulators; partial sums
 // go to a slab [wave][2][DIN*DOUT] that a second kernel folds in wave order (deterministic).
@@ -324,6 +492,9 @@ int launch_fwd(const float* Nn, const float* X, const float* W1, const float* W2
   const size_t lds = sizeof(float) * 2 * DIN * S::LDW;
   const int64_t tiles = (n + 63) / 64;
   const unsigned grid = static_cast<unsigned>(tiles < 1024 ? tiles : 1024);
+  if (lds > 64 * 1024)
+    TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ngcf_fwd_kernel<DIN, DOUT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
   ngcf_fwd_kernel<DIN, DOUT><<<grid, kNgcfThreads, lds, s>>>(Nn, X, W1, W2, n, Xp, inv, Z, ldz);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
@@ -333,16 +504,31 @@ template <int DIN, int DOUT>
 int launch_bwd(const float* dXp, const NormGrad& ng, const float* Nn, const float* X, const float* W1, const float* W2, int64_t n,
                float* dNn, float* dXd, float* dP1, float* dP2, hipStream_t s) {
   using S = NgcfShape<DIN, DOUT>;
-  const size_t lds = sizeof(float) * (2 * DIN * S::LDW + 2 * DOUT * S::LDT);
   const int64_t tiles = (n + 63) / 64;
-  const unsigned grid = static_cast<unsigned>(tiles < 1024 ? tiles : 1024);
-  auto kern = ng.Xp ? ngcf_bwd_kernel<DIN, DOUT, true> : ngcf_bwd_kernel<DIN, DOUT, false>;
-  if (lds > 64 * 1024)
-    TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(lds)));
-  kern<<<grid, kNgcfThreads, lds, s>>>(dXp, ng, Nn, X, W1, W2, n, dNn, dXd, dP1, dP2);
-  TAGREC_LAUNCH_CHECK();
-  return TAGREC_OK;
+  if constexpr (S::kBig) {
+    // one matrix per launch: k-major + transposed copy of ONE matrix in LDS (see the header)
+    const size_t lds1 = sizeof(float) * (DIN * S::LDW + DOUT * S::LDT);
+    const unsigned grid1 = static_cast<unsigned>(tiles < 256 ? tiles : 256);
+    auto k1 = ng.Xp ? ngcf_bwd_one_kernel<DIN, DOUT, true, 1> : ngcf_bwd_one_kernel<DIN, DOUT, false, 1>;
+    auto k2 = ng.Xp ? ngcf_bwd_one_kernel<DIN, DOUT, true, 2> : ngcf_bwd_one_kernel<DIN, DOUT, false, 2>;
+    TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds1)));
+    TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds1)));
+    k1<<<grid1, kNgcfThreads, lds1, s>>>(dXp, ng, Nn, X, W1, n, dNn, dXd, dP1);
+    TAGREC_LAUNCH_CHECK();
+    k2<<<grid1, kNgcfThreads, lds1, s>>>(dXp, ng, Nn, X, W2, n, dNn, dXd, dP2);
+    TAGREC_LAUNCH_CHECK();
+    return TAGREC_OK;
+  } else {
+    const size_t lds = sizeof(float) * (2 * DIN * S::LDW + 2 * DOUT * S::LDT);
+    const unsigned grid = static_cast<unsigned>(tiles < 1024 ? tiles : 1024);
+    auto kern = ng.Xp ? ngcf_bwd_kernel<DIN, DOUT, true> : ngcf_bwd_kernel<DIN, DOUT, false>;
+    if (lds > 64 * 1024)
+      TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds)));
+    kern<<<grid, kNgcfThreads, lds, s>>>(dXp, ng, Nn, X, W1, W2, n, dNn, dXd, dP1, dP2);
+    TAGREC_LAUNCH_CHECK();
+    return TAGREC_OK;
+  }
 }
 
 template <int DIN, int DOUT>
@@ -354,7 +540,13 @@ int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float*
   constexpr int kWavesPerBlock = kNgcfThreads / 64;
   const int64_t waves = steps > 0 ? (steps + per - 1) / per : 1;      // n == 0: one block writes zero partials
   const unsigned blocks = static_cast<unsigned>((waves + kWavesPerBlock - 1) / kWavesPerBlock);
-  ngcf_wgrad_kernel<DIN, DOUT><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws);
+  if constexpr (NgcfShape<DIN, DOUT>::kBig) {
+    ngcf_wgrad_one_kernel<DIN, DOUT, 1><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, n, per, ws);
+    TAGREC_LAUNCH_CHECK();
+    ngcf_wgrad_one_kernel<DIN, DOUT, 2><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP2, n, per, ws);
+  } else {
+    ngcf_wgrad_kernel<DIN, DOUT><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws);
+  }
   TAGREC_LAUNCH_CHECK();
   const int elems = DIN * DOUT;
   ngcf_wgrad_reduce_kernel<<<(2 * elems + 63) / 64, 64 * kReduceParts, 0, s>>>(ws, static_cast<int>(blocks) * kWavesPerBlock, elems, dW1, dW2);
@@ -371,10 +563,10 @@ int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float*
     case 64016: return CALL(64, 16);   case 64032: return CALL(64, 32);                     \
     case 64064: return CALL(64, 64);   case 64128: return CALL(64, 128);                    \
     case 128016: return CALL(128, 16); case 128032: return CALL(128, 32);                   \
-    case 128064: return CALL(128, 64);                                                      \
+    case 128064: return CALL(128, 64); case 128128: return CALL(128, 128);                  \
     default: break;                                                                         \
   }                                                                                         \
-  return fail(TAGREC_E_UNSUPPORTED, "ngcf: layer widths must be 16, 32, 64 or 128 and not 128 -> 128 (got " +  \
+  return fail(TAGREC_E_UNSUPPORTED, "ngcf: layer widths must be 16, 32, 64 or 128 (got " +  \
                                         std::to_string(Din) + " -> " + std::to_string(Dout) + ")")
 
 }  // namespace tagrec

@@ -292,7 +292,7 @@ class NGCF(TableModel):
 
     def _fused_ok(self):
         dl = self.dim_layer_list
-        dims_ok = all(d in (16, 32, 64, 128) for d in dl) and all(a * b < 128 * 128 for a, b in zip(dl[:-1], dl[1:]))
+        dims_ok = all(d in (16, 32, 64, 128) for d in dl)
         return isinstance(self.norm_adj, Graph) and dims_ok
 
     def _drops(self):

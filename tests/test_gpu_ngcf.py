@@ -89,7 +89,7 @@ def test_ngcf_unfused_path_matches_fused(golden):
         _grad_close(m2.mat[k].grad.cpu().numpy(), m.mat[k].grad.cpu().numpy(), k, scale)
 
 
-@pytest.mark.parametrize("din,dout", [(64, 64), (64, 32), (32, 16), (16, 64), (128, 64), (16, 16), (64, 128)])
+@pytest.mark.parametrize("din,dout", [(64, 64), (64, 32), (32, 16), (16, 64), (128, 64), (16, 16), (64, 128), (128, 128)])
 def test_dense_layer_kernels_vs_torch(din, dout):
     """The three MFMA kernels in isolation against torch autograd (fp64 reference), ragged row count."""
     torch.manual_seed(din * 7 + dout)
@@ -118,11 +118,34 @@ def test_dense_layer_kernels_vs_torch(din, dout):
 
 
 def test_unsupported_width_is_reported_not_miscomputed():
-    x = torch.randn(64, 128, device=DEV)
-    w = torch.randn(128, 128, device=DEV)
-    with pytest.raises(T.TagrecError, match="128 -> 128"):
-        NG.dense_forward(x, x, w, w, torch.empty(64, 128, device=DEV), torch.empty(64, device=DEV),
-                         torch.empty(64, 128, device=DEV), 128)
+    x = torch.randn(64, 48, device=DEV)
+    w = torch.randn(48, 48, device=DEV)
+    with pytest.raises(T.TagrecError, match="48 -> 48"):
+        NG.dense_forward(x, x, w, w, torch.empty(64, 48, device=DEV), torch.empty(64, device=DEV),
+                         torch.empty(64, 48, device=DEV), 48)
+
+
+def test_ngcf_128_wide_layers_run_fused(golden):
+    """128 -> 128 layers (one matrix per launch in the backward kernels): the model stays on the fused path and a training
+    step gives the losses and gradients of the operator-by-operator path (SpMM kernel + torch matmul / autograd)."""
+    ds = T.synth.make_cf_dataset(300, 250, 6000, seed=4)
+    cfg = T.get_config("ngcf", use_tag=False, dim_layer_list=[128, 128], dim_latent=128, device=DEV, reg=1e-3)
+    torch.manual_seed(0)
+    m = T.NGCF(ds, config=cfg)
+    m.train()
+    assert m._fused_ok()
+    b = torch.from_numpy(T.synth.sample_bpr_epoch(ds, 0)[:64]).to(DEV)
+    l1 = m.loss(b)
+    sum(l1).backward()
+    got = {k: v.grad.clone() for k, v in m.named_parameters()}
+    m.zero_grad()
+    m._fused_ok = lambda: False                      # operator path
+    l2 = m.loss(b)
+    sum(l2).backward()
+    np.testing.assert_allclose([float(v) for v in l1], [float(v) for v in l2], rtol=1e-5)
+    scale = max(float(v.grad.abs().max()) for v in m.parameters())
+    for k, v in m.named_parameters():
+        _grad_close(got[k].cpu().numpy(), v.grad.cpu().numpy(), k, scale)
 
 
 @pytest.mark.parametrize("layers", [[64, 64, 32], [64, 32], [32]])
