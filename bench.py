@@ -356,8 +356,10 @@ def main():
         col_ok = D % world == 0 and D // world >= 8
         parallel = "feature" if (world <= 4 and col_ok) else "row"
     Dl = D // world if (sharded and parallel == "feature") else D
-    if args.model != "lightgcn" and world > 1:
-        sys.exit(f"bench.py: the sharded path covers LightGCN (C2/C5); run --model {args.model} on one GPU")
+    if args.model not in ("lightgcn", "ngcf") and sharded:
+        sys.exit(f"bench.py: the sharded path covers LightGCN (C2/C5) and NGCF (C3); run --model {args.model} on one GPU")
+    if args.model == "ngcf" and sharded:
+        parallel, Dl = "row", D                 # W1 / W2 mix the columns: NGCF shards by rows only
     routed = args.model in ("dgcf", "disengcn")
 
     t0 = time.perf_counter()
@@ -375,11 +377,15 @@ def main():
         if not routed:
             G.transpose()                  # NGCF: build A^T once, outside the timed region
     else:
-        if parallel == "feature":
+        if args.model == "ngcf":
+            model = TD.ShardedNGCF(ds, cfg, rp, col, val, n, n_chunks=args.chunks or None)
+            timed_graph = model.graph_chunks[0]
+        elif parallel == "feature":
             model = TD.FeatureShardedLightGCN(ds, cfg, rp, col, val, n)
+            timed_graph = model.graph
         else:
             model = TD.ShardedLightGCN(ds, cfg, rp, col, val, n, n_chunks=args.chunks or None)
-        timed_graph = model.graph
+            timed_graph = model.graph
         del rp, col, val
     opt = T.Adam(model.parameters(), lr=cfg["lr"])
     torch.cuda.synchronize()
@@ -479,7 +485,7 @@ def main():
     if sharded and parallel == "feature":
         dom, epi_row_bytes = "spmm_ss", 4                  # Y = A X on D/N columns + one float of row sum-of-squares
     fwd = kernel_ms.get(dom, [])
-    n_local_rows = timed_graph.shape[0]
+    n_local_rows = model.per if row_sharded else timed_graph.shape[0]     # (a shard is walked in row blocks: whole shard)
     local_nnz = timed_graph.nnz
     alg = spmm_bytes(local_nnz, n_local_rows, Dl, epi_row_bytes)
     if routed:

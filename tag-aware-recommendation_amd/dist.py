@@ -122,6 +122,15 @@ class HipOps:
                    "bpr_bwd")
 
 
+    # -- NGCF dense block (csrc/ngcf.hip)
+    def ngcf_dense_fwd(self, nei, x, w1p, w2p, xp, inv, z_slot, ldz):
+        from .ngcf import dense_forward
+        dense_forward(nei, x, w1p, w2p, xp, inv, z_slot, ldz)
+
+    def ngcf_dense_bwd(self, dxp, nei, x, w1p, w2p, norm):
+        from .ngcf import dense_backward
+        return dense_backward(dxp, nei, x, w1p, w2p, norm=norm)
+
     # -- column-sharded tables -------------------------------------------------------------------
     def spmm_axpy(self, g, g_in, b, s, out):
         g.spmm_axpy(g_in, b, s, out)
@@ -609,6 +618,160 @@ class ShardedLightGCN(torch.nn.Module):
 
     def gathered_table(self):
         return self.all_gather(self.table.detach())[:self.n_nodes]
+
+
+# ====================================================================================== NGCF, row-sharded
+class _ShardedNgcfLoss(torch.autograd.Function):
+    """(table shard, W / b) -> [mul_loss, l2reg_loss(propagated rows)] for a replicated batch; see ShardedNGCF."""
+
+    @staticmethod
+    def forward(ctx, model, trip, table, *mats):
+        from .ngcf import _wps
+        m, ops, part = model, model.ops, model.part
+        x0 = table.detach()
+        dims = m.dims
+        L, dtot = len(dims) - 1, sum(dims)
+        dev = x0.device
+        wps = _wps([t.detach() for t in mats])
+        out = torch.empty(part.per, dtot, dtype=torch.float32, device=dev)
+        out[:, :dims[0]] = x0
+        saved, x, off = [], x0, dims[0]
+        for k, (w1p, w2p) in enumerate(wps):
+            xf = _Gather(m, x.shape[1], key=("ngcf_fwd", k & 1)).put_all(x).table()
+            nei = torch.empty_like(x)
+            for c in range(part.n_chunks):
+                r = part.chunk_rows(c)
+                ops.spmm_plain(m.graph_chunks[c], xf, nei[r])
+            xp = torch.empty(part.per, dims[k + 1], dtype=torch.float32, device=dev)
+            inv = torch.empty(part.per, dtype=torch.float32, device=dev)
+            ops.ngcf_dense_fwd(nei, x, w1p, w2p, xp, inv, out[:, off:], dtot)
+            saved.append((x, nei, xp, inv, w1p, w2p))
+            x, off = xp, off + dims[k + 1]
+        B = trip.shape[0]
+        T = 3 * B
+        rows = torch.cat([trip[:, 0], m.n_user + trip[:, 1], m.n_user + trip[:, 2]])
+        slot = torch.nonzero(part.owner(rows) == m.rank).flatten()
+        loc = rows[slot] - m.lo
+        out_b = torch.zeros(T, dtot, dtype=torch.float32, device=dev)
+        out_b.index_copy_(0, slot, out.index_select(0, loc))
+        m.all_reduce(out_b, "batch_rows")
+        ar = torch.arange(B, device=dev)
+        ctrip = torch.stack([ar, ar, ar + B], dim=1).contiguous()
+        res, coef = ops.bpr_fwd(out_b[:B], out_b[B:], out_b[:B], out_b[B:], ctrip, H.loss_kind_id(m.loss_func))
+        ctx.m, ctx.saved, ctx.out_b, ctx.ctrip, ctx.coef, ctx.slot, ctx.loc = m, saved, out_b, ctrip, coef, slot, loc
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ngcf import _mat_grads
+        m, saved, out_b, ctrip = ctx.m, ctx.saved, ctx.out_b, ctx.ctrip
+        ops, part, dims = m.ops, m.part, m.dims
+        B = ctrip.shape[0]
+        dtot = sum(dims)
+        dev = out_b.device
+        d_b = torch.zeros_like(out_b)
+        # NGCF regularises the PROPAGATED rows: both loss parts send their gradient into the same compact rows
+        ops.bpr_bwd(out_b[:B], out_b[B:], out_b[:B], out_b[B:], ctrip, ctx.coef, g.contiguous(), d_b[:B], d_b[B:], d_b[:B], d_b[B:])
+        d_out = torch.zeros(part.per, dtot, dtype=torch.float32, device=dev)
+        d_out.index_add_(0, ctx.loc, d_b[ctx.slot])
+        offs = [0]
+        for d in dims:
+            offs.append(offs[-1] + d)
+        dws = [None] * len(saved)
+        dx_next = None
+        for k in range(len(saved) - 1, -1, -1):
+            x, nei, xp, inv, w1p, w2p = saved[k]
+            d_nei, d_xd, dw1, dw2 = ops.ngcf_dense_bwd(dx_next, nei, x, w1p, w2p, (xp, inv, d_out[:, offs[k + 1]:], dtot))
+            dws[k] = (dw1, dw2)
+            # dX = dX_direct + (A^T dN)[rows_g]: A = D^-1 A + I is not symmetric, the rank holds rows_g of A^T
+            gf = _Gather(m, d_nei.shape[1], key=("ngcf_bwd", k & 1)).put_all(d_nei).table()
+            dx = torch.empty_like(x)
+            for c in range(part.n_chunks):
+                r = part.chunk_rows(c)
+                ops.spmm_axpy(m.graph_t_chunks[c], gf, d_xd[r], 1.0, dx[r])
+            dx_next = dx
+        d0 = dx_next + d_out[:, :dims[0]] if dx_next is not None else d_out[:, :dims[0]].contiguous()
+        gm = _mat_grads(dws)
+        if gm:                                        # every rank summed its own rows: one small all-reduce for W / b
+            flat = torch.cat([t.reshape(-1) for t in gm])
+            m.all_reduce(flat, "weight_grads")
+            o = 0
+            for i, t in enumerate(gm):
+                gm[i] = flat[o:o + t.numel()].reshape(t.shape)
+                o += t.numel()
+        ctx.saved = None
+        return (None, None, d0, *gm)
+
+
+class ShardedNGCF(torch.nn.Module):
+    """NGCF (model/ngcf.py) with the node table ROW-sharded over the ranks of the process group, the reference's
+    `split_adj_k` folds (adj.py:114-140,158-164) living on different GPUs.  Rank g owns rows_g of the table (parameters,
+    Adam state), the row slice A[rows_g, :] and the row slice of A^T (A = D^-1 A + I is not symmetric); W / b are
+    replicated and their gradients all-reduced.  Per layer, forward and backward: one pipelined all-gather (of X, of dN),
+    the local product, the local MFMA dense block.  Every layer runs on all rows (the restricted step of the single-GPU
+    model is not ported).  Same `loss(batch)` / `parameters()` surface as `NGCF`; every rank calls with the same batch."""
+
+    def __init__(self, data, config, rowptr, col, val, n_nodes, ops=None, group=None, n_chunks=None):
+        super().__init__()
+        self.ops = ops if ops is not None else HipOps()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(config["device"])
+        self.dims = tuple([config["dim_latent"]] + list(config["dim_layer_list"]))
+        self.reg = config["reg"]
+        self.loss_func = config["mul_loss_func"]
+        if config.get("agg_type", "bi_agg") != "bi_agg":
+            raise NotImplementedError                     # ngcf.py:65-68
+        self.n_user, self.n_item = data.num["user"], data.num["item"]
+        self.n_nodes = int(n_nodes)
+        if n_chunks is None:
+            n_chunks = 4 if self.world > 1 else 1
+        self.part = RowPartition(self.n_nodes, self.world, n_chunks)
+        self.per, self.n_pad = self.part.per, self.part.n_pad
+        self.lo, self.hi = self.rank * self.per, (self.rank + 1) * self.per
+
+        def row_blocks(rp_g, c_g, v_g):
+            rp, c, v = local_csr(rp_g, c_g, v_g, self.lo, self.hi, self.per)
+            c = self.part.gathered(c.to(torch.int64)).to(torch.int32).contiguous()
+            return [self.ops.row_block(rp, c, v, k * self.part.rc, (k + 1) * self.part.rc, self.n_pad) for k in range(n_chunks)]
+
+        self.graph_chunks = row_blocks(rowptr, col, val)
+        self.graph_t_chunks = row_blocks(*transpose_csr(rowptr, col, val, self.n_nodes))
+        num_list = [self.n_user, self.n_item] + ([data.num["tag"]] if config["use_tag"] else [])
+        assert sum(num_list) == self.n_nodes
+        full = xavier_tables(num_list, self.dims[0], "cpu")            # same seed on every rank -> same table, same W / b
+        local = torch.zeros(self.per, self.dims[0])
+        real_hi = min(self.hi, self.n_nodes)
+        if real_hi > self.lo:
+            local[:real_hi - self.lo] = full[self.lo:real_hi]
+        del full
+        self.table = torch.nn.Parameter(local.to(self.device))
+        self.mat = torch.nn.ParameterDict()
+        for k in range(len(self.dims) - 1):                            # the reference's registration order (ngcf.py:45-60)
+            for name in (f"W1_{k}", f"b1_{k}", f"W2_{k}", f"b2_{k}"):
+                t = torch.empty(self.dims[k] if name[0] == "W" else 1, self.dims[k + 1])
+                torch.nn.init.xavier_uniform_(t)
+                self.mat[name] = torch.nn.Parameter(t.to(self.device))
+        self._buffers_cache = {}
+        self.timing = None
+        self.comm_bytes = 0
+
+    _scratch = ShardedLightGCN._scratch
+    _wait_begin = ShardedLightGCN._wait_begin
+    _wait_end = ShardedLightGCN._wait_end
+    timing_ms = ShardedLightGCN.timing_ms
+    all_gather = ShardedLightGCN.all_gather
+    all_reduce = ShardedLightGCN.all_reduce
+    gathered_table = ShardedLightGCN.gathered_table
+
+    def _mats(self):
+        return [self.mat[f"{n}_{k}"] for k in range(len(self.dims) - 1) for n in ("W1", "b1", "W2", "b2")]
+
+    def loss(self, batch_data):
+        batch_data = batch_data.to(self.device, torch.int64).contiguous()
+        res = _ShardedNgcfLoss.apply(self, batch_data, self.table, *self._mats())
+        return res[0], self.reg * res[1]
 
 
 # ====================================================================================== feature sharding

@@ -133,6 +133,25 @@ class CpuOps:
         y[keep] = full[keep]
         ss[keep] = (full[keep] ** 2).sum(1)
 
+    # -- NGCF dense block (same contract as tagrec_amd.ngcf.dense_forward / dense_backward)
+    def ngcf_dense_fwd(self, nei, x, w1p, w2p, xp, inv, z_slot, ldz):
+        lr = torch.nn.functional.leaky_relu
+        xp.copy_(lr((nei + x) @ w1p, 0.2) + lr((nei * x) @ w2p, 0.2))
+        den = xp.norm(dim=1).clamp_min(1e-12)
+        inv.copy_(1.0 / den)
+        z_slot[:, :xp.shape[1]] = xp / den[:, None]
+
+    def ngcf_dense_bwd(self, dxp, nei, x, w1p, w2p, norm):
+        xp, inv, dz, _ = norm
+        gx = self._nb(xp, inv, dz[:, :xp.shape[1]])
+        if dxp is not None:
+            gx = gx + dxp
+        a1, a2 = nei + x, nei * x
+        slope = lambda p: torch.where(p > 0, torch.ones_like(p), torch.full_like(p, 0.2))
+        dp1, dp2 = gx * slope(a1 @ w1p), gx * slope(a2 @ w2p)
+        da1, da2 = dp1 @ w1p.t(), dp2 @ w2p.t()
+        return da1 + da2 * x, da1 + da2 * nei, a1.t() @ dp1, a2.t() @ dp2
+
     # -- column-sharded tables
     def spmm_axpy(self, g, g_in, b, s, out):
         out.copy_(g @ g_in + s * b)
@@ -366,6 +385,73 @@ def test_sharded_lightgcn_rejects_asymmetric_normalisation(tmp_path):
     port = _free_port()
     mp.spawn(_asym_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert "not symmetric" in open(tmp_path / "msg.txt").read()
+
+
+def _ngcf_worker(rank, world, port, out_dir, n_chunks):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tagrec_amd as T
+    from tagrec_amd import dist as TD
+    from oracle import adj as oadj
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        fx = load_golden("ngcf_toy")
+        csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "ngcf")
+        cfg = T.get_config("ngcf", use_tag=True, dim_layer_list=[int(v) for v in fx["layers"]], dim_latent=int(fx["D"]),
+                           reg=float(fx["reg"]), device="cpu")
+        ds = T.synth.Dataset()
+        ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
+        torch.manual_seed(2020)
+        m = TD.ShardedNGCF(ds, cfg, torch.from_numpy(csr.rowptr), torch.from_numpy(csr.col), torch.from_numpy(csr.val),
+                           csr.shape[0], ops=CpuOps(), n_chunks=n_chunks)
+        full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)])
+        with torch.no_grad():
+            m.table.zero_()
+            hi = min(m.hi, full.shape[0])
+            if hi > m.lo:
+                m.table[:hi - m.lo] = full[m.lo:hi]
+            for k, p in m.mat.items():
+                p.copy_(torch.from_numpy(fx["init.mat." + k]))
+        opt = torch.optim.Adam(m.parameters(), lr=0.01)
+        losses, grads = [], {}
+        for b in fx["batches"][:3]:
+            lossx = m.loss(torch.from_numpy(b))
+            losses.append([float(x) for x in lossx])
+            opt.zero_grad()
+            sum(lossx).backward()
+            if len(losses) == 1:
+                grads = {"table": m.all_gather(m.table.grad)[:full.shape[0]].clone().numpy()}
+                grads.update({"mat." + k: p.grad.clone().numpy() for k, p in m.mat.items()})
+            opt.step()
+        table = m.gathered_table()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "ngcf.npz"), losses=np.array(losses), table=table.numpy(),
+                     **{"g." + k: v for k, v in grads.items()}, **{"p." + k: p.detach().numpy() for k, p in m.mat.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_chunks", [(2, 1), (3, 2)])
+def test_row_sharded_ngcf_matches_reference_fixture(tmp_path, golden, world, n_chunks):
+    """Row-sharded NGCF (non-symmetric D^-1 A + I: the backward multiplies by the rank's rows of A^T; W / b replicated,
+    their gradients all-reduced) against the reference's own run: loss parts, every gradient, parameters after 3 steps."""
+    port = _free_port()
+    mp.spawn(_ngcf_worker, args=(world, port, str(tmp_path), n_chunks), nprocs=world, join=True)
+    got = np.load(tmp_path / "ngcf.npz")
+    fx = golden("ngcf_toy")
+    np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
+    np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=1e-5)
+    want_g = np.concatenate([fx[f"grad.embed.{t}"] for t in range(3)])
+    scale = np.abs(want_g).max()
+    np.testing.assert_allclose(got["g.table"], want_g, rtol=2e-3, atol=1e-6 * scale)
+    for k in [f for f in fx if f.startswith("grad.mat.")]:
+        np.testing.assert_allclose(got["g." + k[5:]], fx[k], rtol=2e-3, atol=1e-6 * max(scale, np.abs(fx[k]).max()), err_msg=k)
+    want_t = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
+    assert np.abs(got["table"] - want_t).max() <= 2e-4
+    for k in [f for f in fx if f.startswith("step3.mat.")]:
+        assert np.abs(got["p." + k[10:]] - fx[k]).max() <= 2e-4, k
 
 
 def test_row_partition_layout():

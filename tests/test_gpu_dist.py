@@ -197,3 +197,60 @@ def test_bench_starts_its_own_ranks():
     assert c["world_size_seen_by_torch_distributed"] == 2 and c["row_blocks_per_shard"] >= 1
     assert "all_gather_wait" in c["compute_stream_wait_ms_per_step"] and c["probe"]["all_gather_block_ms"] > 0
     assert line["config"]["parallelism"].startswith("row-shard")
+
+
+def _ngcf_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tagrec_amd as T
+    from tagrec_amd import dist as TD
+    from oracle import adj as oadj
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        fx = load_golden("ngcf_toy")
+        csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "ngcf")
+        cfg = T.get_config("ngcf", use_tag=True, dim_layer_list=[int(v) for v in fx["layers"]], dim_latent=int(fx["D"]),
+                           reg=float(fx["reg"]), device=dev)
+        ds = T.synth.Dataset()
+        ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
+        m = TD.ShardedNGCF(ds, cfg, torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.col).to(dev),
+                           torch.from_numpy(csr.val).to(dev), csr.shape[0], n_chunks=2)
+        full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)]).to(dev)
+        with torch.no_grad():
+            m.table.zero_()
+            hi = min(m.hi, full.shape[0])
+            m.table[:hi - m.lo] = full[m.lo:hi]
+            for k, p in m.mat.items():
+                p.copy_(torch.from_numpy(fx["init.mat." + k]).to(dev))
+        opt = T.Adam(m.parameters(), lr=0.01)
+        losses = []
+        for b in fx["batches"][:3]:
+            lossx = m.loss(torch.from_numpy(b).to(dev))
+            losses.append([float(x) for x in lossx])
+            opt.zero_grad()
+            sum(lossx).backward()
+            opt.step()
+        table = m.gathered_table()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "ngcf.npz"), losses=np.array(losses), table=table.cpu().numpy()[:full.shape[0]],
+                     **{"p." + k: p.detach().cpu().numpy() for k, p in m.mat.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_row_sharded_ngcf_real_kernels(tmp_path, golden):
+    """Row-sharded NGCF on two ranks with the real kernels (product on the rank's rows of A and of A^T, MFMA dense block,
+    all-reduced W / b gradients) against the parameters the reference reached after three Adam steps."""
+    port = _free_port()
+    mp.spawn(_ngcf_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "ngcf.npz")
+    fx = golden("ngcf_toy")
+    np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
+    np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=2e-5)
+    want = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
+    assert np.abs(got["table"] - want).max() <= 2e-4
+    for k in [f for f in fx if f.startswith("step3.mat.")]:
+        assert np.abs(got["p." + k[10:]] - fx[k]).max() <= 2e-4, k
