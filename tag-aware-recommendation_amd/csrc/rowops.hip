@@ -432,23 +432,47 @@ __global__ __launch_bounds__(kThreads) void transtag_bwd_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// Adam, 16 B per lane, grid-stride.  28 B of traffic per element.
-__global__ __launch_bounds__(kThreads) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
-                                                        float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+// Adam, 16 B per lane, grid-stride, two iterations (eight 16-byte loads) in flight per lane; every array is streamed
+// once per step and is far larger than the caches, so all accesses are non-temporal.  28 B of traffic per element.
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ adam_f4 adam_update(adam_f4& mi, adam_f4& vi, adam_f4 pi, const adam_f4 gi, float w1, float b2, float w2,
+                                               float step_size, float bc2_sqrt, float eps) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    mi[c] = mi[c] + w1 * (gi[c] - mi[c]);             /* exp_avg.lerp_(grad, 1-b1)            */
+    vi[c] = vi[c] * b2 + (w2 * gi[c]) * gi[c];        /* mul_(b2).addcmul_(grad, grad, 1-b2)  */
+    pi[c] = pi[c] - step_size * (mi[c] / (sqrtf(vi[c]) / bc2_sqrt + eps));
+  }
+  return pi;
+}
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(float4* __restrict__ p_, const float4* __restrict__ g_,
+                                                        float4* __restrict__ m_, float4* __restrict__ v_, int64_t n4,
                                                         float w1, float b2, float w2, float step_size,
                                                         float bc2_sqrt, float eps, const float* __restrict__ coef) {
   if (coef) { step_size = coef[0]; bc2_sqrt = coef[1]; }      // step-dependent factors kept on the device (graph capture)
+  adam_f4* p = reinterpret_cast<adam_f4*>(p_);
+  const adam_f4* g = reinterpret_cast<const adam_f4*>(g_);
+  adam_f4* m = reinterpret_cast<adam_f4*>(m_);
+  adam_f4* v = reinterpret_cast<adam_f4*>(v_);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
-    const float4 gi = g[i];
-    float4 mi = m[i], vi = v[i], pi = p[i];
-#define TAGREC_ADAM1(c)                                            \
-    mi.c = mi.c + w1 * (gi.c - mi.c);             /* exp_avg.lerp_(grad, 1-b1)            */ \
-    vi.c = vi.c * b2 + (w2 * gi.c) * gi.c;        /* mul_(b2).addcmul_(grad, grad, 1-b2)  */ \
-    pi.c = pi.c - step_size * (mi.c / (sqrtf(vi.c) / bc2_sqrt + eps));
-    TAGREC_ADAM1(x) TAGREC_ADAM1(y) TAGREC_ADAM1(z) TAGREC_ADAM1(w)
-#undef TAGREC_ADAM1
-    m[i] = mi; v[i] = vi; p[i] = pi;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const int64_t j = i + stride;
+    const adam_f4 g0 = __builtin_nontemporal_load(g + i), g1 = __builtin_nontemporal_load(g + j);
+    adam_f4 m0 = __builtin_nontemporal_load(m + i), m1 = __builtin_nontemporal_load(m + j);
+    adam_f4 v0 = __builtin_nontemporal_load(v + i), v1 = __builtin_nontemporal_load(v + j);
+    const adam_f4 p0 = __builtin_nontemporal_load(p + i), p1 = __builtin_nontemporal_load(p + j);
+    const adam_f4 q0 = adam_update(m0, v0, p0, g0, w1, b2, w2, step_size, bc2_sqrt, eps);
+    const adam_f4 q1 = adam_update(m1, v1, p1, g1, w1, b2, w2, step_size, bc2_sqrt, eps);
+    __builtin_nontemporal_store(m0, m + i); __builtin_nontemporal_store(v0, v + i); __builtin_nontemporal_store(q0, p + i);
+    __builtin_nontemporal_store(m1, m + j); __builtin_nontemporal_store(v1, v + j); __builtin_nontemporal_store(q1, p + j);
+  }
+  if (i < n4) {
+    const adam_f4 g0 = __builtin_nontemporal_load(g + i);
+    adam_f4 m0 = __builtin_nontemporal_load(m + i), v0 = __builtin_nontemporal_load(v + i);
+    const adam_f4 q0 = adam_update(m0, v0, __builtin_nontemporal_load(p + i), g0, w1, b2, w2, step_size, bc2_sqrt, eps);
+    __builtin_nontemporal_store(m0, m + i); __builtin_nontemporal_store(v0, v + i); __builtin_nontemporal_store(q0, p + i);
   }
 }
 

@@ -456,11 +456,17 @@ __global__ __launch_bounds__(256) void spmm_listed_fold_kernel(const float* __re
 template <bool SELF>
 __global__ __launch_bounds__(256) void mark_rows_kernel(GraphView g, const int64_t* __restrict__ rows, int64_t n_listed,
                                                         uint8_t* __restrict__ flags) {
-  const int64_t i = blockIdx.x;
+  // every listed row is cut into kListedSplits ranges (batch rows are popular items: 1e5 entries), one block each
+  const int64_t i = blockIdx.x / kListedSplits;
+  const int part = blockIdx.x % kListedSplits;
   if (i >= n_listed) return;
   const int64_t r = rows[i];
-  if (SELF && threadIdx.x == 0) flags[r] = 1;
-  for (int64_t j = g.rowptr[r] + threadIdx.x; j < g.rowptr[r + 1]; j += blockDim.x) flags[g.col[j]] = 1;
+  if (SELF && part == 0 && threadIdx.x == 0) flags[r] = 1;
+  const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
+  const int64_t per = (end - start + kListedSplits - 1) / kListedSplits;
+  const int64_t b0 = start + part * per;
+  const int64_t b1 = (b0 + per < end) ? b0 + per : end;
+  for (int64_t j = b0 + threadIdx.x; j < b1; j += blockDim.x) flags[g.col[j]] = 1;
 }
 
 // ---- row-length scan at graph creation ---------------------------------------------------------
@@ -894,10 +900,10 @@ extern "C" int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* r
                                          void* stream) {
   TAGREC_REQUIRE(g != nullptr && flags != nullptr && (n_listed == 0 || rows != nullptr), "graph_mark_rows: null pointer");
   TAGREC_REQUIRE(g->n_rows == g->n_cols, "graph_mark_rows: square adjacency expected (flags are indexed by node)");
-  TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "graph_mark_rows: bad row count");
+  TAGREC_REQUIRE(n_listed >= 0 && n_listed * kListedSplits < (1ll << 31), "graph_mark_rows: bad row count");
   if (n_listed == 0) return TAGREC_OK;
   const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
-  mark_rows_kernel<true><<<static_cast<unsigned>(n_listed), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
+  mark_rows_kernel<true><<<static_cast<unsigned>(n_listed * kListedSplits), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
@@ -905,10 +911,10 @@ extern "C" int tagrec_graph_mark_rows_u8(const tagrec_graph* g, const int64_t* r
 extern "C" int tagrec_graph_mark_cols_u8(const tagrec_graph* g, const int64_t* rows, int64_t n_listed, uint8_t* flags,
                                          void* stream) {
   TAGREC_REQUIRE(g != nullptr && flags != nullptr && (n_listed == 0 || rows != nullptr), "graph_mark_cols: null pointer");
-  TAGREC_REQUIRE(n_listed >= 0 && n_listed < (1ll << 31), "graph_mark_cols: bad row count");
+  TAGREC_REQUIRE(n_listed >= 0 && n_listed * kListedSplits < (1ll << 31), "graph_mark_cols: bad row count");
   if (n_listed == 0) return TAGREC_OK;
   const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
-  mark_rows_kernel<false><<<static_cast<unsigned>(n_listed), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
+  mark_rows_kernel<false><<<static_cast<unsigned>(n_listed * kListedSplits), 256, 0, static_cast<hipStream_t>(stream)>>>(gv, rows, n_listed, flags);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
