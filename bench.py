@@ -13,12 +13,12 @@ sampled on the device beforehand (the reference also times its sampler separatel
 With N > 1 the SAME graph and batch are split over N ranks, one per GPU (strong scaling).  Launch either
 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` or as plain
 `python bench.py --gpus N`: the latter starts the N ranks itself (fresh child processes; the parent
-never touches the GPU).  `--parallel row` (default from 8 ranks): the node table, Adam state and CSR
+never touches the GPU).  `--parallel row` (default from 8 ranks at dim 64): the node table, Adam state and CSR
 rows are sharded by row range -- the reference's split_adj_k folds (adj.py:114-140,158-164), one per GPU
 -- and the step is the restricted one of the single-GPU model: block-wise pipelined all-gathers of the
 layers that need every row, the top layer in push form on the batch rows, flagged gradient tables
-(tagrec_amd/dist.py).  `--parallel feature` (default up to 4 ranks, where the row partition's 4 table shards per step and link cost more
-than the step itself): every rank holds D/N columns of every row plus the whole CSR; only row
+(tagrec_amd/dist.py).  `--parallel feature` (default up to 4 ranks, and whenever dim / ranks >= 32 as at C5: a column slice then still
+gathers whole 128-byte rows): every rank holds D/N columns of every row plus the whole CSR; only row
 norms, row dot products and the B triplet scores are all-reduced.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused forward layer on all rows
@@ -353,8 +353,11 @@ def main():
         # per step and its per-rank step was measured on one rank's slice: 7.5 / 6.9 / 6.5 ms (32 / 16 / 8 columns; below
         # 32 columns a gathered row is shorter than the 128-byte line).  Projected step, row vs column: 2 ranks 20 vs 7.6 ms,
         # 4 ranks 10.4 vs 7.0 ms, 8 ranks 5.4 vs 6.6 ms: columns up to 4 ranks, rows from 8.
+        # At D / ranks >= 32 (C5: 256 / 8) a column slice still gathers whole 128-byte rows and exchanges nothing but three
+        # small all-reduces: one rank's slice of the C5 shape runs at 79 ms against 436 ms for the whole problem on one
+        # GPU (5.5x at 8 ranks), where the row partition would move 4 x 2.56 GB per link and step (~160 ms).
         col_ok = D % world == 0 and D // world >= 8
-        parallel = "feature" if (world <= 4 and col_ok) else "row"
+        parallel = "feature" if (col_ok and (D // world >= 32 or world <= 4)) else "row"
     Dl = D // world if (sharded and parallel == "feature") else D
     if args.model not in ("lightgcn", "ngcf") and sharded:
         sys.exit(f"bench.py: the sharded path covers LightGCN (C2/C5) and NGCF (C3); run --model {args.model} on one GPU")
@@ -537,12 +540,16 @@ def main():
 
     if rank == 0:
         mname = {"lightgcn": "LightGCN", "ngcf": "NGCF", "dgcf": "DGCF", "disengcn": "DisenGCN"}[args.model]
+        cfg_tag = {"lightgcn": "C2", "ngcf": "C3"}.get(args.model, "C2-graph")
+        if args.scale != 1.0 or (args.model in ("lightgcn", "ngcf") and D != 64):
+            cfg_tag = ("C5-shape (10M x 10M x 500M edges, dim 256) on ONE GPU" if (args.model == "lightgcn" and args.scale == 10.0
+                       and D == 256 and world == 1) else f"{cfg_tag}-shaped (scale {args.scale:g}, dim {D})")
         size = "1M users x 1M items x 50M edges" if args.scale == 1.0 else f"{nu} users x {ni} items x {ne} edges"
         out = {"metric": f"BPR triplets/sec, {mname} {L}-layer dim{D}, {size}",
                "value": K * B / dt, "unit": "triplets/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": dt / K * 1e3, "higher_is_better": True,
                "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{ {'lightgcn': 'C2', 'ngcf': 'C3'}.get(args.model, 'C2-graph') } {mname} L={L} D={D} users={nu} items={ni} "
+               "config": {"workload": f"{cfg_tag} {mname} L={L} D={D} users={nu} items={ni} "
                                       f"edges={ne} nnz={nnz} train_batch={B} adam lr=0.01 {cfg['norm_type']} {cfg['mul_loss_func']}",
                           "train_batch": B, "parallelism": f"{parallel}-shard x{world}" if sharded else "single",
                           "step": "loss -> backward -> Adam on one batch; same loss and gradients as the all-rows step: rows "

@@ -196,6 +196,7 @@ def restricted_backward(graph_t, rows, d_out_b, state, shape):
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
         graph_t.spmm_normbwd_sparse(g, flags, count, raws[k], invs[k], dz, s, gn, fo, cnt, row_mask=mid if masked else None,
                                     dz_flags=tflag)
+        raws[k] = invs[k] = None          # last use: the 4 N D bytes go back to the allocator before the next hop allocates
         # a masked hop wrote the rows of `mid` only: its flags must always be honoured; a full hop wrote every row
         g, flags, count = gn, fo, (None if masked else cnt)
     g0 = torch.empty(n, D, dtype=torch.float32, device=dev)
