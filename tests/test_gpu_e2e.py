@@ -160,6 +160,37 @@ def test_c2_fused_layer_consistent_with_plain_spmm(c2_graph):
     np.testing.assert_allclose(inv.cpu().numpy(), (1.0 / plain.norm(dim=1).clamp_min(1e-12)).cpu().numpy(), rtol=1e-5)
 
 
+def test_c5_width_restricted_step_equals_all_rows_step_at_full_c2_size(c2_graph):
+    """C5's row width (dim 256, 3 layers) at the full C2 graph size (2 M nodes, nnz 100 M, rows of 1e5 entries): the
+    restricted training step -- all-rows layer, row-masked layer, compact push-form top layer, flagged backward with
+    packed entries, batch-row epilogue terms -- against the step that computes every layer on all rows: same loss parts,
+    same table gradient.  (The whole C5 shape, 10 M x 10 M x 500 M edges, runs on one GPU too: tools/c5_one_gpu.py.)"""
+    g, e = c2_graph
+    nu = ni = 1_000_000
+    ds = T.synth.Dataset()
+    ds.num = {"user": nu, "item": ni}
+    cfg = T.get_config("lightgcn", use_tag=False, dim_latent=256, dim_layer_list=[256] * 3, device=DEV, train_batch=512, reg=1e-3)
+    torch.manual_seed(5)
+    m = T.LightGCN(ds, config=cfg, graph=g)
+    m.train()
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    pick = torch.randint(0, e.shape[0], (512,), device=DEV, generator=gen)
+    batch = torch.stack([e[pick, 0], e[pick, 1], torch.randint(0, ni, (512,), device=DEV, generator=gen)], 1)
+    res = []
+    for restrict in (False, True):
+        m.restrict_forward = restrict
+        m.zero_grad()
+        lossx = m.loss(batch)
+        sum(lossx).backward()
+        res.append(([float(v) for v in lossx], m.table.grad.clone()))
+        m.table.grad = None
+    (l0, g0), (l1, g1) = res
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)
+    scale = float(g0.abs().max())
+    # |difference| <= 1e-3 |gradient| + 1e-5 of the largest entry, element by element (other summation order)
+    assert float(((g1 - g0).abs() - 1e-3 * g0.abs()).max()) <= 1e-5 * scale
+
+
 @pytest.fixture(scope="module")
 def c3_graph(c2_graph):
     """C3 = the C2 graph under NGCF's normalisation D^-1 A + I (adj.py:82-83): not symmetric, so the backward multiplies by
