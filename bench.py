@@ -436,7 +436,7 @@ def main():
     timed_graphs = model.graph_chunks if row_sharded else [timed_graph]
     for g_ in timed_graphs:
         g_.timing = {}
-    if row_sharded:
+    if sharded:
         model.timing, model.comm_bytes = {}, 0
     dt, last = timed(batches[W:])
     per_block = [g_.timing_ms() for g_ in timed_graphs]
@@ -445,12 +445,14 @@ def main():
         g_.timing = None
     loss_val = [float(x) for x in last]
     comm = None
-    if row_sharded:
+    if sharded:
         waits = model.timing_ms()
         model.timing = None
         comm = {"world_size_seen_by_torch_distributed": dist.get_world_size(), "backend": dist.get_backend(),
-                "row_blocks_per_shard": model.part.n_chunks, "rows_per_rank": model.part.per,
-                "bytes_received_per_rank_per_step": model.comm_bytes / K,
+                "row_blocks_per_shard": model.part.n_chunks if row_sharded else None,
+                "rows_per_rank": model.part.per if row_sharded else n,
+                "columns_per_rank": D if row_sharded else Dl,
+                "bytes_exchanged_per_rank_per_step": model.comm_bytes / K,
                 "compute_stream_wait_ms_per_step": {k: sum(v) / K for k, v in waits.items()},
                 "collectives_per_step": {k: len(v) / K for k, v in waits.items()},
                 "probe": probe}

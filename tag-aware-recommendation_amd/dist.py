@@ -996,10 +996,20 @@ class FeatureShardedLightGCN(torch.nn.Module):
         full = xavier_tables(num_list, self.dim_latent, "cpu")          # same seed on every rank -> same table
         lo = self.rank * self.dim_local
         self.table = torch.nn.Parameter(full[:, lo:lo + self.dim_local].contiguous().to(self.device))
+        self.timing = None
+        self.comm_bytes = 0
 
-    def all_reduce(self, x):
+    # collectives: timed / counted like the row-sharded model's (bench.py prints them)
+    _wait_begin = ShardedLightGCN._wait_begin
+    _wait_end = ShardedLightGCN._wait_end
+    timing_ms = ShardedLightGCN.timing_ms
+
+    def all_reduce(self, x, name="all_reduce"):
         if self.world > 1:
+            e = self._wait_begin()
+            self.comm_bytes += x.numel() * x.element_size()
             dist.all_reduce(x, group=self.group)
+            self._wait_end(e, name)
         return x
 
     restrict_min_ratio = 16          # the restricted step is used when 3 B * this <= number of nodes

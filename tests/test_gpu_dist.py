@@ -177,7 +177,8 @@ def test_sharded_restricted_step_equals_single_gpu_model(tmp_path, D, n_chunks, 
         np.testing.assert_allclose(r["i2"], r["i1"], rtol=1e-4, atol=1e-5)
 
 
-def test_bench_starts_its_own_ranks():
+@pytest.mark.parametrize("parallel", ["row", "feature"])
+def test_bench_starts_its_own_ranks(parallel):
     """`python bench.py --gpus 2` outside torch.distributed.run starts two fresh rank processes.  On a one-GPU box the
     ranks share cuda:0 and exchange through gloo (--share-gpu); what is checked is the launcher, the row-sharded step
     end to end on a scaled-down C2 graph, and the shape of the JSON line."""
@@ -185,7 +186,7 @@ def test_bench_starts_its_own_ranks():
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--parallel", "row", "--scale", "0.05", "--steps", "3",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--parallel", parallel, "--scale", "0.05", "--steps", "3",
            "--warmup", "1", "--no-cpu", "--big-batch", "0"]
     if torch.cuda.device_count() < 2:
         cmd.append("--share-gpu")
@@ -194,9 +195,13 @@ def test_bench_starts_its_own_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     c = line["extra"]["collectives"]
-    assert c["world_size_seen_by_torch_distributed"] == 2 and c["row_blocks_per_shard"] >= 1
-    assert "all_gather_wait" in c["compute_stream_wait_ms_per_step"] and c["probe"]["all_gather_block_ms"] > 0
-    assert line["config"]["parallelism"].startswith("row-shard")
+    assert c["world_size_seen_by_torch_distributed"] == 2 and c["bytes_exchanged_per_rank_per_step"] > 0
+    if parallel == "row":
+        assert c["row_blocks_per_shard"] >= 1 and c["probe"]["all_gather_block_ms"] > 0
+        assert "all_gather_wait" in c["compute_stream_wait_ms_per_step"]
+    else:
+        assert c["columns_per_rank"] == 32 and c["collectives_per_step"]["all_reduce"] == 3.0    # norms, dots, nb dots
+    assert line["config"]["parallelism"].startswith(f"{parallel}-shard")
 
 
 def _ngcf_worker(rank, world, port, out_dir):
