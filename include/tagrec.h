@@ -322,7 +322,15 @@ int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* v, int64_t 
  *         (tagrec_spmm_axpy_f32).
  *   wgrad: dW1p = (N + X)^T dP1, dW2p = (N * X)^T dP2 (deterministic two-stage reduction; workspace of
  *         tagrec_ngcf_wgrad_workspace(Din, Dout) floats).  db = column sums of dWp (the bias broadcast).
- * Din, Dout in {16, 32, 64, 128}, except 128 -> 128 (the LDS copies of W' would not fit): TAGREC_E_UNSUPPORTED. */
+ * Din, Dout in {16, 32, 64, 128} (128 -> 128 runs the backward kernels one matrix per launch: both LDS copies of both
+ * matrices would not fit).
+ * The *_rows_* forms serve the restricted training step (a layer whose output is needed on some rows only):
+ *   row_mask (one byte per row, may be NULL = every row): rows whose byte is 0 are neither read nor written -- their
+ *     slots in the outputs keep whatever they held, so every consumer must be handed the same mask (the weight gradient
+ *     takes it too and counts such rows as zero);
+ *   Z may be NULL (fwd): the normalised slot is not written (the step forms it on the batch rows from Xp and inv_norm);
+ *   dz_flags (bwd, one byte per row, may be NULL): rows whose byte is 0 have dZ == 0; Xp, inv_norm and dZ are not read
+ *     there (the concat gradient of a BPR step lives on the <= 3 B batch rows). */
 int64_t tagrec_ngcf_wgrad_workspace(int Din, int Dout);
 int tagrec_ngcf_dense_fwd_f32(const float* N, const float* X, const float* W1p, const float* W2p,
                               int64_t n_rows, int Din, int Dout, float* Xp, float* inv_norm, float* Z,
@@ -339,6 +347,16 @@ int tagrec_ngcf_dense_bwd_norm_f32(const float* G, const float* Xp, const float*
 int tagrec_ngcf_wgrad_f32(const float* N, const float* X, const float* dP1, const float* dP2, int64_t n_rows,
                           int Din, int Dout, float* dW1p, float* dW2p, float* workspace,
                           int64_t workspace_floats, void* stream);
+int tagrec_ngcf_dense_fwd_rows_f32(const float* N, const float* X, const float* W1p, const float* W2p,
+                                   int64_t n_rows, int Din, int Dout, float* Xp, float* inv_norm, float* Z,
+                                   int64_t ldz, const uint8_t* row_mask, void* stream);
+int tagrec_ngcf_dense_bwd_rows_f32(const float* G, const float* Xp, const float* inv_norm, const float* dZ, int64_t ldz,
+                                   const uint8_t* dz_flags, const float* N, const float* X, const float* W1p,
+                                   const float* W2p, int64_t n_rows, int Din, int Dout, float* dN, float* dXd,
+                                   float* dP1, float* dP2, const uint8_t* row_mask, void* stream);
+int tagrec_ngcf_wgrad_rows_f32(const float* N, const float* X, const float* dP1, const float* dP2, int64_t n_rows,
+                               int Din, int Dout, float* dW1p, float* dW2p, float* workspace,
+                               int64_t workspace_floats, const uint8_t* row_mask, void* stream);
 
 /* ---- TGCN neighbour-level attention (tgcn.py:20-37) over fixed-width neighbour tables (tgcn.py:194-202) ---
  * The caller forms the dense pieces with plain GEMMs:  P = ev W1[:D] + b  [n, A];  Q = ej W2  [m, A];

@@ -61,6 +61,13 @@ _SIGNATURES = {
                                        c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_ngcf_wgrad_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                               c_void_p, c_int64, c_void_p],
+    "tagrec_ngcf_dense_fwd_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_int64, c_void_p, c_void_p],
+    "tagrec_ngcf_dense_bwd_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p],
+    "tagrec_ngcf_wgrad_rows_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_tgcn_attn_workspace": [c_int, c_int],
     "tagrec_tgcn_attn_fwd_f32": [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tagrec_tgcn_attn_bwd_f32": [c_void_p] * 9 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [c_int64, c_void_p],

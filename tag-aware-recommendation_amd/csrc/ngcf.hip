@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kNgcfThreads, (NgcfShape<DIN, DOUT>::kOcc)) void ng
                                                                 const float* __restrict__ W1, const float* __restrict__ W2,
                                                                 int64_t n_rows, float* __restrict__ Xp,
                                                                 float* __restrict__ inv_norm, float* __restrict__ Z,
-                                                                int64_t ldz) {
+                                                                int64_t ldz, const uint8_t* __restrict__ row_mask) {
   using S = NgcfShape<DIN, DOUT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   load_weights<DIN, DOUT, false>(W1, W2, lds);
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(kNgcfThreads, (NgcfShape<DIN, DOUT>::kOcc)) void ng
   const int64_t n_tiles = (n_rows + 63) / 64;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 64 + wave * 16 + r;
-    const bool ok = row < n_rows;
+    const bool ok = row < n_rows && (!row_mask || row_mask[row]);
+    if (row_mask && !__any(ok)) continue;                    // none of the wave's 16 rows is wanted (wave-uniform)
     f32x4 nn[S::IB], x[S::IB], a1[S::IB], a2[S::IB], p1[S::MB], p2[S::MB];
     load_inputs<DIN>(Nn, X, row, ok, q, nn, x);
 #pragma unroll
@@ -171,9 +172,11 @@ __global__ __launch_bounds__(kNgcfThreads, (NgcfShape<DIN, DOUT>::kOcc)) void ng
 #pragma unroll
       for (int mb = 0; mb < S::MB; ++mb) {
         *reinterpret_cast<f32x4*>(Xp + row * DOUT + mb * 16 + q * 4) = p1[mb];
-        f32x4 z = p1[mb];
-        z[0] /= den; z[1] /= den; z[2] /= den; z[3] /= den;
-        *reinterpret_cast<f32x4*>(Z + row * ldz + mb * 16 + q * 4) = z;
+        if (Z) {
+          f32x4 z = p1[mb];
+          z[0] /= den; z[1] /= den; z[2] /= den; z[3] /= den;
+          *reinterpret_cast<f32x4*>(Z + row * ldz + mb * 16 + q * 4) = z;
+        }
       }
       if (q == 0) inv_norm[row] = 1.0f / den;
     }
@@ -189,6 +192,7 @@ struct NormGrad {
   const float* inv;
   const float* dZ;
   int64_t ldz;
+  const uint8_t* dz_flags;     // may be null; rows whose byte is 0 have dZ == 0: neither Xp nor dZ is read there
 };
 
 template <int DIN, int DOUT, bool NORM>
@@ -197,7 +201,8 @@ __global__ __launch_bounds__(kNgcfThreads) void ngcf_bwd_kernel(const float* __r
                                                                 const float* __restrict__ X, const float* __restrict__ W1,
                                                                 const float* __restrict__ W2, int64_t n_rows,
                                                                 float* __restrict__ dNn, float* __restrict__ dXd,
-                                                                float* __restrict__ dP1, float* __restrict__ dP2) {
+                                                                float* __restrict__ dP1, float* __restrict__ dP2,
+                                                                const uint8_t* __restrict__ row_mask) {
   using S = NgcfShape<DIN, DOUT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   load_weights<DIN, DOUT, true>(W1, W2, lds);
@@ -208,7 +213,8 @@ __global__ __launch_bounds__(kNgcfThreads) void ngcf_bwd_kernel(const float* __r
   const int64_t n_tiles = (n_rows + 63) / 64;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 64 + wave * 16 + r;
-    const bool ok = row < n_rows;
+    const bool ok = row < n_rows && (!row_mask || row_mask[row]);
+    if (row_mask && !__any(ok)) continue;                    // rows outside the mask: nothing read, nothing written
     f32x4 nn[S::IB], x[S::IB], a1[S::IB], a2[S::IB], p1[S::MB], p2[S::MB];
     load_inputs<DIN>(Nn, X, row, ok, q, nn, x);
 #pragma unroll
@@ -222,13 +228,14 @@ __global__ __launch_bounds__(kNgcfThreads) void ngcf_bwd_kernel(const float* __r
     }
     if constexpr (NORM) {
       f32x4 z[S::MB], dz[S::MB];
-      const float inv = ok ? ng.inv[row] : 0.f;
+      const bool nz = ok && (!ng.dz_flags || ng.dz_flags[row]);
+      const float inv = nz ? ng.inv[row] : 0.f;
       float dot = 0.f;
 #pragma unroll
       for (int mb = 0; mb < S::MB; ++mb) {
         z[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
         dz[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok) {
+        if (nz) {
           z[mb] = *reinterpret_cast<const f32x4*>(ng.Xp + row * DOUT + mb * 16 + q * 4) * inv;
           dz[mb] = *reinterpret_cast<const f32x4*>(ng.dZ + row * ng.ldz + mb * 16 + q * 4);
         }
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_bwd_one_kernel(const flo
                                                                     const float* __restrict__ Nn, const float* __restrict__ X,
                                                                     const float* __restrict__ W, int64_t n_rows,
                                                                     float* __restrict__ dNn, float* __restrict__ dXd,
-                                                                    float* __restrict__ dP) {
+                                                                    float* __restrict__ dP, const uint8_t* __restrict__ row_mask) {
   using S = NgcfShape<DIN, DOUT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   load_weights_one<DIN, DOUT>(W, lds);
@@ -294,7 +301,8 @@ __global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_bwd_one_kernel(const flo
   const int64_t n_tiles = (n_rows + 63) / 64;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 64 + wave * 16 + r;
-    const bool ok = row < n_rows;
+    const bool ok = row < n_rows && (!row_mask || row_mask[row]);
+    if (row_mask && !__any(ok)) continue;
     f32x4 nn[S::IB], x[S::IB], a[S::IB], p[S::MB];
     load_inputs<DIN>(Nn, X, row, ok, q, nn, x);
 #pragma unroll
@@ -307,11 +315,12 @@ __global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_bwd_one_kernel(const flo
       if (ok && dXp) gx[mb] = *reinterpret_cast<const f32x4*>(dXp + row * DOUT + mb * 16 + q * 4);
     }
     if constexpr (NORM) {
-      const float inv = ok ? ng.inv[row] : 0.f;
+      const bool nz = ok && (!ng.dz_flags || ng.dz_flags[row]);
+      const float inv = nz ? ng.inv[row] : 0.f;
       float dot = 0.f;
 #pragma unroll
       for (int mb = 0; mb < S::MB; ++mb) {
-        if (ok) {
+        if (nz) {
           const f32x4 z = *reinterpret_cast<const f32x4*>(ng.Xp + row * DOUT + mb * 16 + q * 4) * inv;
           const f32x4 dz = *reinterpret_cast<const f32x4*>(ng.dZ + row * ng.ldz + mb * 16 + q * 4);
 #pragma unroll
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_bwd_one_kernel(const flo
       if (inv >= 1e12f) dot = 0.f;
 #pragma unroll
       for (int mb = 0; mb < S::MB; ++mb) {
-        if (ok) {                                              // (re-read: holding z and dz would cost 64 registers)
+        if (nz) {                                              // (re-read: holding z and dz would cost 64 registers)
           const f32x4 z = *reinterpret_cast<const f32x4*>(ng.Xp + row * DOUT + mb * 16 + q * 4) * inv;
           const f32x4 dz = *reinterpret_cast<const f32x4*>(ng.dZ + row * ng.ldz + mb * 16 + q * 4);
 #pragma unroll
@@ -367,7 +376,8 @@ __global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_bwd_one_kernel(const flo
 template <int DIN, int DOUT, int MAT>
 __global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_wgrad_one_kernel(const float* __restrict__ Nn, const float* __restrict__ X,
                                                                       const float* __restrict__ dP, int64_t n_rows,
-                                                                      int64_t steps_per_wave, float* __restrict__ slab) {
+                                                                      int64_t steps_per_wave, float* __restrict__ slab,
+                                                                      const uint8_t* __restrict__ row_mask) {
   constexpr int IB = DIN / 16, JB = DOUT / 16;
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, q = lane >> 4;
@@ -381,7 +391,8 @@ __global__ __launch_bounds__(kNgcfThreads, 1) void ngcf_wgrad_one_kernel(const f
   for (int64_t s = s0; s < s0 + steps_per_wave; ++s) {
     const int64_t row = s * 4 + q;
     if (s * 4 >= n_rows) break;
-    const bool ok = row < n_rows;
+    const bool ok = row < n_rows && (!row_mask || row_mask[row]);
+    if (row_mask && !__any(ok)) continue;                    // rows outside the mask contribute nothing
     float a[IB], b[JB];
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
@@ -412,7 +423,7 @@ template <int DIN, int DOUT>
 __global__ __launch_bounds__(kNgcfThreads, 2) void ngcf_wgrad_kernel(const float* __restrict__ Nn, const float* __restrict__ X,
                                                                   const float* __restrict__ dP1, const float* __restrict__ dP2,
                                                                   int64_t n_rows, int64_t steps_per_wave,
-                                                                  float* __restrict__ slab) {
+                                                                  float* __restrict__ slab, const uint8_t* __restrict__ row_mask) {
   constexpr int IB = DIN / 16, JB = DOUT / 16;
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, q = lane >> 4;
@@ -426,7 +437,8 @@ __global__ __launch_bounds__(kNgcfThreads, 2) void ngcf_wgrad_kernel(const float
   for (int64_t s = s0; s < s0 + steps_per_wave; ++s) {
     const int64_t row = s * 4 + q;
     if (s * 4 >= n_rows) break;
-    const bool ok = row < n_rows;
+    const bool ok = row < n_rows && (!row_mask || row_mask[row]);
+    if (row_mask && !__any(ok)) continue;                    // rows outside the mask contribute nothing
     float a1[IB], a2[IB], b1[JB], b2[JB];
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
@@ -487,7 +499,7 @@ constexpr int kWgradWaves = kWgradBlocks * (kNgcfThreads / 64);
 
 template <int DIN, int DOUT>
 int launch_fwd(const float* Nn, const float* X, const float* W1, const float* W2, int64_t n, float* Xp, float* inv,
-               float* Z, int64_t ldz, hipStream_t s) {
+               float* Z, int64_t ldz, const uint8_t* row_mask, hipStream_t s) {
   using S = NgcfShape<DIN, DOUT>;
   const size_t lds = sizeof(float) * 2 * DIN * S::LDW;
   const int64_t tiles = (n + 63) / 64;
@@ -495,14 +507,14 @@ int launch_fwd(const float* Nn, const float* X, const float* W1, const float* W2
   if (lds > 64 * 1024)
     TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ngcf_fwd_kernel<DIN, DOUT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-  ngcf_fwd_kernel<DIN, DOUT><<<grid, kNgcfThreads, lds, s>>>(Nn, X, W1, W2, n, Xp, inv, Z, ldz);
+  ngcf_fwd_kernel<DIN, DOUT><<<grid, kNgcfThreads, lds, s>>>(Nn, X, W1, W2, n, Xp, inv, Z, ldz, row_mask);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
 
 template <int DIN, int DOUT>
 int launch_bwd(const float* dXp, const NormGrad& ng, const float* Nn, const float* X, const float* W1, const float* W2, int64_t n,
-               float* dNn, float* dXd, float* dP1, float* dP2, hipStream_t s) {
+               float* dNn, float* dXd, float* dP1, float* dP2, const uint8_t* row_mask, hipStream_t s) {
   using S = NgcfShape<DIN, DOUT>;
   const int64_t tiles = (n + 63) / 64;
   if constexpr (S::kBig) {
@@ -513,9 +525,9 @@ int launch_bwd(const float* dXp, const NormGrad& ng, const float* Nn, const floa
     auto k2 = ng.Xp ? ngcf_bwd_one_kernel<DIN, DOUT, true, 2> : ngcf_bwd_one_kernel<DIN, DOUT, false, 2>;
     TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds1)));
     TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds1)));
-    k1<<<grid1, kNgcfThreads, lds1, s>>>(dXp, ng, Nn, X, W1, n, dNn, dXd, dP1);
+    k1<<<grid1, kNgcfThreads, lds1, s>>>(dXp, ng, Nn, X, W1, n, dNn, dXd, dP1, row_mask);
     TAGREC_LAUNCH_CHECK();
-    k2<<<grid1, kNgcfThreads, lds1, s>>>(dXp, ng, Nn, X, W2, n, dNn, dXd, dP2);
+    k2<<<grid1, kNgcfThreads, lds1, s>>>(dXp, ng, Nn, X, W2, n, dNn, dXd, dP2, row_mask);
     TAGREC_LAUNCH_CHECK();
     return TAGREC_OK;
   } else {
@@ -525,7 +537,7 @@ int launch_bwd(const float* dXp, const NormGrad& ng, const float* Nn, const floa
     if (lds > 64 * 1024)
       TAGREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
-    kern<<<grid, kNgcfThreads, lds, s>>>(dXp, ng, Nn, X, W1, W2, n, dNn, dXd, dP1, dP2);
+    kern<<<grid, kNgcfThreads, lds, s>>>(dXp, ng, Nn, X, W1, W2, n, dNn, dXd, dP1, dP2, row_mask);
     TAGREC_LAUNCH_CHECK();
     return TAGREC_OK;
   }
@@ -533,7 +545,7 @@ int launch_bwd(const float* dXp, const NormGrad& ng, const float* Nn, const floa
 
 template <int DIN, int DOUT>
 int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float* dP2, int64_t n, float* dW1, float* dW2,
-                 float* ws, hipStream_t s) {
+                 float* ws, const uint8_t* row_mask, hipStream_t s) {
   const int64_t steps = (n + 3) / 4;
   int64_t per = (steps + kWgradWaves - 1) / kWgradWaves;
   if (per < 8) per = 8;                 // small graphs: fewer waves, so the fold below walks fewer partials
@@ -541,11 +553,11 @@ int launch_wgrad(const float* Nn, const float* X, const float* dP1, const float*
   const int64_t waves = steps > 0 ? (steps + per - 1) / per : 1;      // n == 0: one block writes zero partials
   const unsigned blocks = static_cast<unsigned>((waves + kWavesPerBlock - 1) / kWavesPerBlock);
   if constexpr (NgcfShape<DIN, DOUT>::kBig) {
-    ngcf_wgrad_one_kernel<DIN, DOUT, 1><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, n, per, ws);
+    ngcf_wgrad_one_kernel<DIN, DOUT, 1><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, n, per, ws, row_mask);
     TAGREC_LAUNCH_CHECK();
-    ngcf_wgrad_one_kernel<DIN, DOUT, 2><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP2, n, per, ws);
+    ngcf_wgrad_one_kernel<DIN, DOUT, 2><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP2, n, per, ws, row_mask);
   } else {
-    ngcf_wgrad_kernel<DIN, DOUT><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws);
+    ngcf_wgrad_kernel<DIN, DOUT><<<blocks, kNgcfThreads, 0, s>>>(Nn, X, dP1, dP2, n, per, ws, row_mask);
   }
   TAGREC_LAUNCH_CHECK();
   const int elems = DIN * DOUT;
@@ -577,17 +589,24 @@ extern "C" int64_t tagrec_ngcf_wgrad_workspace(int Din, int Dout) {
   return static_cast<int64_t>(kWgradWaves) * 2 * Din * Dout;
 }
 
-extern "C" int tagrec_ngcf_dense_fwd_f32(const float* Nn, const float* X, const float* W1p, const float* W2p,
-                                         int64_t n_rows, int Din, int Dout, float* Xp, float* inv_norm, float* Z,
-                                         int64_t ldz, void* stream) {
-  TAGREC_REQUIRE(Nn && X && W1p && W2p && Xp && inv_norm && Z, "ngcf_dense_fwd: null pointer");
-  TAGREC_REQUIRE(n_rows >= 0 && ldz >= Dout && (ldz % 4) == 0, "ngcf_dense_fwd: bad shape (ldz must be a multiple of 4)");
+extern "C" int tagrec_ngcf_dense_fwd_rows_f32(const float* Nn, const float* X, const float* W1p, const float* W2p,
+                                              int64_t n_rows, int Din, int Dout, float* Xp, float* inv_norm, float* Z,
+                                              int64_t ldz, const uint8_t* row_mask, void* stream) {
+  TAGREC_REQUIRE(Nn && X && W1p && W2p && Xp && inv_norm, "ngcf_dense_fwd: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && (!Z || (ldz >= Dout && (ldz % 4) == 0)), "ngcf_dense_fwd: bad shape (ldz must be a multiple of 4)");
   TAGREC_REQUIRE(aligned16(Nn) && aligned16(X) && aligned16(Xp) && aligned16(Z), "ngcf_dense_fwd: rows must be 16-byte aligned");
   if (n_rows == 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(A, B) launch_fwd<A, B>(Nn, X, W1p, W2p, n_rows, Xp, inv_norm, Z, ldz, s)
+#define CALL(A, B) launch_fwd<A, B>(Nn, X, W1p, W2p, n_rows, Xp, inv_norm, Z, ldz, row_mask, s)
   TAGREC_NGCF_DISPATCH(CALL);
 #undef CALL
+}
+
+extern "C" int tagrec_ngcf_dense_fwd_f32(const float* Nn, const float* X, const float* W1p, const float* W2p,
+                                         int64_t n_rows, int Din, int Dout, float* Xp, float* inv_norm, float* Z,
+                                         int64_t ldz, void* stream) {
+  TAGREC_REQUIRE(Z, "ngcf_dense_fwd: null pointer");
+  return tagrec_ngcf_dense_fwd_rows_f32(Nn, X, W1p, W2p, n_rows, Din, Dout, Xp, inv_norm, Z, ldz, nullptr, stream);
 }
 
 extern "C" int tagrec_ngcf_dense_bwd_f32(const float* dXp, const float* Nn, const float* X, const float* W1p,
@@ -599,8 +618,24 @@ extern "C" int tagrec_ngcf_dense_bwd_f32(const float* dXp, const float* Nn, cons
                      aligned16(dP2), "ngcf_dense_bwd: rows must be 16-byte aligned");
   if (n_rows == 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const NormGrad ng{nullptr, nullptr, nullptr, 0};
-#define CALL(A, B) launch_bwd<A, B>(dXp, ng, Nn, X, W1p, W2p, n_rows, dNn, dXd, dP1, dP2, s)
+  const NormGrad ng{nullptr, nullptr, nullptr, 0, nullptr};
+#define CALL(A, B) launch_bwd<A, B>(dXp, ng, Nn, X, W1p, W2p, n_rows, dNn, dXd, dP1, dP2, nullptr, s)
+  TAGREC_NGCF_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int tagrec_ngcf_dense_bwd_rows_f32(const float* G, const float* Xp, const float* inv_norm, const float* dZ, int64_t ldz,
+                                              const uint8_t* dz_flags, const float* Nn, const float* X, const float* W1p,
+                                              const float* W2p, int64_t n_rows, int Din, int Dout, float* dNn, float* dXd,
+                                              float* dP1, float* dP2, const uint8_t* row_mask, void* stream) {
+  TAGREC_REQUIRE(Xp && inv_norm && dZ && Nn && X && W1p && W2p && dNn && dXd && dP1 && dP2, "ngcf_dense_bwd_norm: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && ldz >= Dout && ldz % 4 == 0, "ngcf_dense_bwd_norm: bad shape");
+  TAGREC_REQUIRE(aligned16(G) && aligned16(Xp) && aligned16(dZ) && aligned16(Nn) && aligned16(X) && aligned16(dNn) &&
+                     aligned16(dXd) && aligned16(dP1) && aligned16(dP2), "ngcf_dense_bwd_norm: rows must be 16-byte aligned");
+  if (n_rows == 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const NormGrad ng{Xp, inv_norm, dZ, ldz, dz_flags};
+#define CALL(A, B) launch_bwd<A, B>(G, ng, Nn, X, W1p, W2p, n_rows, dNn, dXd, dP1, dP2, row_mask, s)
   TAGREC_NGCF_DISPATCH(CALL);
 #undef CALL
 }
@@ -609,14 +644,17 @@ extern "C" int tagrec_ngcf_dense_bwd_norm_f32(const float* G, const float* Xp, c
                                               const float* Nn, const float* X, const float* W1p, const float* W2p,
                                               int64_t n_rows, int Din, int Dout, float* dNn, float* dXd, float* dP1,
                                               float* dP2, void* stream) {
-  TAGREC_REQUIRE(Xp && inv_norm && dZ && Nn && X && W1p && W2p && dNn && dXd && dP1 && dP2, "ngcf_dense_bwd_norm: null pointer");
-  TAGREC_REQUIRE(n_rows >= 0 && ldz >= Dout && ldz % 4 == 0, "ngcf_dense_bwd_norm: bad shape");
-  TAGREC_REQUIRE(aligned16(G) && aligned16(Xp) && aligned16(dZ) && aligned16(Nn) && aligned16(X) && aligned16(dNn) &&
-                     aligned16(dXd) && aligned16(dP1) && aligned16(dP2), "ngcf_dense_bwd_norm: rows must be 16-byte aligned");
-  if (n_rows == 0) return TAGREC_OK;
+  return tagrec_ngcf_dense_bwd_rows_f32(G, Xp, inv_norm, dZ, ldz, nullptr, Nn, X, W1p, W2p, n_rows, Din, Dout, dNn, dXd, dP1, dP2,
+                                        nullptr, stream);
+}
+
+extern "C" int tagrec_ngcf_wgrad_rows_f32(const float* Nn, const float* X, const float* dP1, const float* dP2, int64_t n_rows,
+                                          int Din, int Dout, float* dW1p, float* dW2p, float* workspace,
+                                          int64_t workspace_floats, const uint8_t* row_mask, void* stream) {
+  TAGREC_REQUIRE(Nn && X && dP1 && dP2 && dW1p && dW2p && workspace, "ngcf_wgrad: null pointer");
+  TAGREC_REQUIRE(workspace_floats >= tagrec_ngcf_wgrad_workspace(Din, Dout), "ngcf_wgrad: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const NormGrad ng{Xp, inv_norm, dZ, ldz};
-#define CALL(A, B) launch_bwd<A, B>(G, ng, Nn, X, W1p, W2p, n_rows, dNn, dXd, dP1, dP2, s)
+#define CALL(A, B) launch_wgrad<A, B>(Nn, X, dP1, dP2, n_rows, dW1p, dW2p, workspace, row_mask, s)
   TAGREC_NGCF_DISPATCH(CALL);
 #undef CALL
 }
@@ -624,10 +662,5 @@ extern "C" int tagrec_ngcf_dense_bwd_norm_f32(const float* G, const float* Xp, c
 extern "C" int tagrec_ngcf_wgrad_f32(const float* Nn, const float* X, const float* dP1, const float* dP2, int64_t n_rows,
                                      int Din, int Dout, float* dW1p, float* dW2p, float* workspace,
                                      int64_t workspace_floats, void* stream) {
-  TAGREC_REQUIRE(Nn && X && dP1 && dP2 && dW1p && dW2p && workspace, "ngcf_wgrad: null pointer");
-  TAGREC_REQUIRE(workspace_floats >= tagrec_ngcf_wgrad_workspace(Din, Dout), "ngcf_wgrad: workspace too small");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(A, B) launch_wgrad<A, B>(Nn, X, dP1, dP2, n_rows, dW1p, dW2p, workspace, s)
-  TAGREC_NGCF_DISPATCH(CALL);
-#undef CALL
+  return tagrec_ngcf_wgrad_rows_f32(Nn, X, dP1, dP2, n_rows, Din, Dout, dW1p, dW2p, workspace, workspace_floats, nullptr, stream);
 }

@@ -21,16 +21,20 @@ from .config import CFG as _GLOBAL_CFG
 from .graph import Graph, creat_adj
 
 
-def dense_forward(nei, x, w1p, w2p, xp, inv, z_slot, ldz):
+def dense_forward(nei, x, w1p, w2p, xp, inv, z_slot, ldz, row_mask=None):
+    """z_slot None: the normalised slot is not written.  row_mask (uint8 per row): rows with a zero byte are neither read
+    nor written."""
     n, din = x.shape
-    _lib.check(_lib.load().tagrec_ngcf_dense_fwd_f32(_lib.ptr(nei), _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n, din,
-                                                     w1p.shape[1], _lib.ptr(xp), _lib.ptr(inv), _lib.ptr(z_slot), ldz,
-                                                     _lib.stream_ptr()), "ngcf_dense_fwd")
+    _lib.check(_lib.load().tagrec_ngcf_dense_fwd_rows_f32(_lib.ptr(nei), _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n, din,
+                                                          w1p.shape[1], _lib.ptr(xp), _lib.ptr(inv), _lib.ptr(z_slot), ldz,
+                                                          _lib.ptr(row_mask), _lib.stream_ptr()), "ngcf_dense_fwd")
 
 
-def dense_backward(dxp, nei, x, w1p, w2p, norm=None):
+def dense_backward(dxp, nei, x, w1p, w2p, norm=None, row_mask=None, dz_flags=None):
     """norm = (xp, inv, dz, ldz): the gradient w.r.t. Xp is dxp (may be None) + normalize-backward of the layer's slot
-    dz of the concat gradient, formed inside the kernel."""
+    dz of the concat gradient, formed inside the kernel (dz_flags: rows with a zero byte have dz == 0 and are not read).
+    row_mask: rows with a zero byte are skipped altogether -- d_nei / d_xd are left unwritten there and the weight
+    gradient counts them as zero."""
     n, din = x.shape
     dout = w1p.shape[1]
     d_nei, d_xd = torch.empty_like(x), torch.empty_like(x)
@@ -38,20 +42,22 @@ def dense_backward(dxp, nei, x, w1p, w2p, norm=None):
     lib = _lib.load()
     if norm is not None:
         xp, inv, dz, ldz = norm
-        _lib.check(lib.tagrec_ngcf_dense_bwd_norm_f32(_lib.ptr(dxp), _lib.ptr(xp), _lib.ptr(inv), _lib.ptr(dz), ldz, _lib.ptr(nei),
-                                                      _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n, din, dout, _lib.ptr(d_nei),
-                                                      _lib.ptr(d_xd), _lib.ptr(dp1), _lib.ptr(dp2), _lib.stream_ptr()),
-                   "ngcf_dense_bwd_norm")
+        _lib.check(lib.tagrec_ngcf_dense_bwd_rows_f32(_lib.ptr(dxp), _lib.ptr(xp), _lib.ptr(inv), _lib.ptr(dz), ldz,
+                                                      _lib.ptr(dz_flags), _lib.ptr(nei), _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p),
+                                                      n, din, dout, _lib.ptr(d_nei), _lib.ptr(d_xd), _lib.ptr(dp1), _lib.ptr(dp2),
+                                                      _lib.ptr(row_mask), _lib.stream_ptr()), "ngcf_dense_bwd_norm")
     else:
+        if row_mask is not None:
+            raise _lib.TagrecError("dense_backward: a row mask needs the fused normalize-backward form (norm=...)")
         _lib.check(lib.tagrec_ngcf_dense_bwd_f32(_lib.ptr(dxp), _lib.ptr(nei), _lib.ptr(x), _lib.ptr(w1p), _lib.ptr(w2p), n,
                                                  din, dout, _lib.ptr(d_nei), _lib.ptr(d_xd), _lib.ptr(dp1), _lib.ptr(dp2),
                                                  _lib.stream_ptr()), "ngcf_dense_bwd")
     ws_n = lib.tagrec_ngcf_wgrad_workspace(din, dout)
     ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
     dw1, dw2 = torch.empty_like(w1p), torch.empty_like(w2p)
-    _lib.check(lib.tagrec_ngcf_wgrad_f32(_lib.ptr(nei), _lib.ptr(x), _lib.ptr(dp1), _lib.ptr(dp2), n, din, dout,
-                                         _lib.ptr(dw1), _lib.ptr(dw2), _lib.ptr(ws), ws_n, _lib.stream_ptr()),
-               "ngcf_wgrad")
+    _lib.check(lib.tagrec_ngcf_wgrad_rows_f32(_lib.ptr(nei), _lib.ptr(x), _lib.ptr(dp1), _lib.ptr(dp2), n, din, dout,
+                                              _lib.ptr(dw1), _lib.ptr(dw2), _lib.ptr(ws), ws_n, _lib.ptr(row_mask),
+                                              _lib.stream_ptr()), "ngcf_wgrad")
     return d_nei, d_xd, dw1, dw2
 
 
@@ -196,6 +202,95 @@ def propagate_backward(graph_t, d_out, saved, dims):
     return (dx_next + d0) if dx_next is not None else d0.contiguous(), dws
 
 
+def _scatter_rows(n, rows, compact):
+    """[n, D] tensor that holds sum of compact[j] over rows[j] == r at the listed rows and is UNWRITTEN elsewhere."""
+    t = torch.empty(n, compact.shape[1], dtype=torch.float32, device=compact.device)
+    t.index_fill_(0, rows, 0.0)
+    return t.index_add_(0, rows, compact)
+
+
+def restricted_forward(graph, x0, wps, dims, rows):
+    """The forward pass of a training step whose loss reads the concatenated output at `rows` (int64 node ids [T], may
+    repeat) only -- the BPR batch rows (ngcf.py:97-101).  Layers below L-1 run on all rows, layer L-1 (neighbour sum AND
+    dense block) on the batch rows and their neighbours (row-masked kernels), layer L in compact form on the T batch
+    rows alone (`spmm_listed` + the dense block on T rows); no layer writes its normalised slot, the concatenated output
+    is formed at the end on the T rows.  Rows a layer did not compute are left UNWRITTEN; every later reader is handed
+    the mask.  A node named by several batch slots is computed once per slot: every backward map is linear in the
+    slot's upstream gradient, so summing the slots' results (index_add) equals using the summed gradient.
+    Returns (out_b [T, sum(dims)], state for `restricted_backward`)."""
+    from .lightgcn import spmm_listed
+    L, n = len(wps), x0.shape[0]
+    mid = graph.mark_rows(rows, torch.zeros(n, dtype=torch.uint8, device=x0.device)) if L >= 2 else None
+    saved, x = [], x0
+    for k in range(L - 1):
+        m = mid if k == L - 2 else None
+        w1p, w2p = wps[k]
+        nei = torch.empty_like(x)
+        if m is None:
+            graph.spmm(x, out=nei)
+        else:
+            graph.spmm_rows(x, nei, m)
+        xp = torch.empty(n, dims[k + 1], dtype=torch.float32, device=x0.device)
+        inv = torch.empty(n, dtype=torch.float32, device=x0.device)
+        dense_forward(nei, x, w1p, w2p, xp, inv, None, 0, m)
+        saved.append((x, nei, xp, inv, w1p, w2p, m))
+        x = xp
+    w1p, w2p = wps[L - 1]
+    d = dims[L]
+    T = rows.numel()
+    nc = spmm_listed(graph, rows, x)
+    xc = x.index_select(0, rows)
+    xpc = torch.empty(T, d, dtype=torch.float32, device=x0.device)
+    invc = torch.empty(T, dtype=torch.float32, device=x0.device)
+    out_b = torch.empty(T, sum(dims), dtype=torch.float32, device=x0.device)
+    off = dims[0]
+    out_b[:, :off] = x0.index_select(0, rows)
+    for (_, _, xp, inv, _, _, _) in saved:
+        torch.mul(xp.index_select(0, rows), inv.index_select(0, rows)[:, None], out=out_b[:, off:off + xp.shape[1]])
+        off += xp.shape[1]
+    dense_forward(nc, xc, w1p, w2p, xpc, invc, out_b[:, off:], out_b.shape[1])
+    return out_b, (saved, mid, (nc, xc, xpc, invc, w1p, w2p))
+
+
+def restricted_backward(graph_t, rows, d_b, state, dims, n):
+    """Gradient of `restricted_forward` given d_b [T, sum(dims)] = d loss / d out_b -> (d_x0 [n, dims[0]], [(dW1', dW2')]).
+    The chain starts on the batch rows (compact), lands on their neighbours (row-masked hop) and spreads from there; the
+    concat gradient of the lower layers lives on the batch rows (dz_flags), the masked layer's dense backward and weight
+    gradient visit the masked rows only, and every product is told which operand rows are valid."""
+    saved, mid, (nc, xc, xpc, invc, w1p, w2p) = state
+    L = len(saved) + 1
+    dtot = d_b.shape[1]
+    offs = [0]
+    for dd in dims:
+        offs.append(offs[-1] + dd)
+    dev = d_b.device
+    dws = [None] * L
+    tflag = torch.zeros(n, dtype=torch.uint8, device=dev)
+    tflag.index_fill_(0, rows, 1)
+    # top layer, one slot per batch row
+    d_nei_c, d_xd_c, dw1, dw2 = dense_backward(None, nc, xc, w1p, w2p, norm=(xpc, invc, d_b[:, offs[L]:], dtot))
+    dws[L - 1] = (dw1, dw2)
+    g, b = _scatter_rows(n, rows, d_nei_c), _scatter_rows(n, rows, d_xd_c)       # valid on the batch rows only
+    dx = torch.empty(n, dims[L - 1], dtype=torch.float32, device=dev)
+    graph_t.spmm_axpy_sparse(g, tflag, None, b, 1.0, dx, mid, b_flags=tflag)     # valid on `mid` (every row if L == 1)
+    if L >= 2:
+        dzn = _scatter_rows(n, rows, d_b[:, offs[1]:offs[L]])                    # concat gradient of layers 1 .. L-1
+        ldz = dzn.shape[1]
+    for k in range(L - 2, -1, -1):
+        x, nei, xp, inv, w1p, w2p, m = saved[k]
+        d_nei, d_xd, dw1, dw2 = dense_backward(dx, nei, x, w1p, w2p, norm=(xp, inv, dzn[:, offs[k + 1] - offs[1]:], ldz),
+                                               row_mask=m, dz_flags=tflag)
+        dws[k] = (dw1, dw2)
+        saved[k] = None
+        dx = torch.empty_like(x)
+        if m is not None:
+            graph_t.spmm_axpy_sparse(d_nei, m, None, d_xd, 1.0, dx, None, b_flags=m)
+        else:
+            graph_t.spmm_axpy(d_nei, d_xd, 1.0, dx)
+    dx.index_add_(0, rows, d_b[:, :dims[0]])
+    return dx, dws
+
+
 def _mat_grads(dws):
     out = []
     for dw1, dw2 in dws:                  # order W1_k, b1_k, W2_k, b2_k (the ParameterDict's order)
@@ -226,22 +321,50 @@ class _PropagateBprLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, graph, dims, n_user, n_item, trip, loss_kind, drops, seed, table, *mats):
-        loss_rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user]) if RESTRICT_FORWARD else None
-        out, saved = propagate_forward(graph, table.detach(), _wps([m.detach() for m in mats]), dims, loss_rows, drops, seed)
-        B, dtot = trip.shape[0], out.shape[1]
-        coef = torch.empty(B, dtype=torch.float32, device=out.device)
-        partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=out.device)
-        res = torch.empty(2, dtype=torch.float32, device=out.device)
+        x0 = table.detach()
+        wps = _wps([m.detach() for m in mats])
+        B, n = trip.shape[0], x0.shape[0]
+        rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user]) if RESTRICT_FORWARD else None
+        coef = torch.empty(B, dtype=torch.float32, device=x0.device)
+        partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=x0.device)
+        res = torch.empty(2, dtype=torch.float32, device=x0.device)
+        ctx.graph, ctx.dims, ctx.trip, ctx.coef, ctx.nu, ctx.ni = graph, dims, trip, coef, n_user, n_item
+        ctx.compact = bool(RESTRICT_FORWARD and drops is None and len(wps) >= 1 and graph.shape[0] == graph.shape[1]
+                           and 3 * B * 16 <= n)                       # a batch that touches most rows gains nothing
+        if ctx.compact:
+            out_b, ctx.state = restricted_forward(graph, x0, wps, dims, rows)
+            dtot = out_b.shape[1]
+            ar = torch.arange(B, device=x0.device)
+            ctrip = torch.stack([ar, ar, ar + B], dim=1).contiguous()
+            U, I = out_b[:B], out_b[B:]
+            _lib.check(_lib.load().tagrec_bpr_fwd_f32(_lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(U), _lib.ptr(I), dtot, dtot,
+                                                      _lib.ptr(ctrip), B, loss_kind, _lib.ptr(coef), _lib.ptr(partials),
+                                                      _lib.ptr(res), _lib.stream_ptr()), "bpr_fwd")
+            ctx.rows, ctx.out_b, ctx.ctrip, ctx.n = rows, out_b, ctrip, n
+            return res
+        out, saved = propagate_forward(graph, x0, wps, dims, rows, drops, seed)
+        dtot = out.shape[1]
         U, I = out[:n_user], out[n_user:n_user + n_item]
         _lib.check(_lib.load().tagrec_bpr_fwd_f32(_lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(U), _lib.ptr(I), dtot,
                                                   dtot, _lib.ptr(trip), B, loss_kind, _lib.ptr(coef),
                                                   _lib.ptr(partials), _lib.ptr(res), _lib.stream_ptr()), "bpr_fwd")
-        ctx.graph, ctx.dims, ctx.saved = graph, dims, saved
-        ctx.out, ctx.trip, ctx.coef, ctx.nu, ctx.ni = out, trip, coef, n_user, n_item
+        ctx.saved, ctx.out = saved, out
         return res
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.compact:
+            out_b, ctrip = ctx.out_b, ctx.ctrip
+            B, dtot = ctrip.shape[0], out_b.shape[1]
+            d_b = torch.zeros_like(out_b)
+            U, I, dU, dI = out_b[:B], out_b[B:], d_b[:B], d_b[B:]
+            _lib.check(_lib.load().tagrec_bpr_bwd_f32(_lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(U), _lib.ptr(I), dtot, dtot,
+                                                      _lib.ptr(ctrip), B, _lib.ptr(ctx.coef), _lib.ptr(g.contiguous()), 1.0,
+                                                      _lib.ptr(dU), _lib.ptr(dI), _lib.ptr(dU), _lib.ptr(dI), _lib.stream_ptr()),
+                       "bpr_bwd")
+            d0, dws = restricted_backward(ctx.graph.transpose(), ctx.rows, d_b, ctx.state, ctx.dims, ctx.n)
+            ctx.state = ctx.out_b = None
+            return (None, None, None, None, None, None, None, None, d0, *_mat_grads(dws))
         out, trip, nu, ni = ctx.out, ctx.trip, ctx.nu, ctx.ni
         dtot = out.shape[1]
         d_out = torch.zeros_like(out)

@@ -178,3 +178,45 @@ def test_restricted_forward_equals_full_forward_step(layers):
     for k in g0:
         a, b = g0[k].double(), g1[k].double()
         assert float((a - b).norm()) <= 1e-3 * float(a.norm()) + 1e-6 * top, k
+
+
+@pytest.mark.parametrize("din,dout", [(64, 64), (32, 64), (128, 128)])
+def test_dense_layer_kernels_row_mask_and_dz_flags(din, dout):
+    """The *_rows_* forms (restricted training step): rows outside row_mask are neither read nor written (their output
+    slots keep a sentinel, their inputs may hold NaN), the weight gradient counts them as zero, and rows with a zero
+    dz_flags byte skip the normalize-backward term; the rows that are computed equal the unmasked kernels' rows."""
+    torch.manual_seed(din + dout)
+    n = 777
+    nei, x = torch.randn(n, din, device=DEV), torch.randn(n, din, device=DEV)
+    w1p, w2p = torch.randn(din, dout, device=DEV) * 0.3, torch.randn(din, dout, device=DEV) * 0.3
+    mask = (torch.rand(n, device=DEV) < 0.3).to(torch.uint8)
+    mask[16:48] = 0                                            # whole 16-row groups without a wanted row
+    mask[n - 5:] = 1
+    keep = mask.bool()
+    dzf = ((torch.rand(n, device=DEV) < 0.2) & keep).to(torch.uint8)
+    # full run
+    xp, inv = torch.empty(n, dout, device=DEV), torch.empty(n, device=DEV)
+    z = torch.empty(n, dout, device=DEV)
+    NG.dense_forward(nei, x, w1p, w2p, xp, inv, z, dout)
+    up, dz = torch.randn(n, dout, device=DEV), torch.randn(n, dout, device=DEV) * dzf[:, None]
+    up_m = up * keep[:, None]
+    ref = NG.dense_backward(up_m, nei, x, w1p, w2p, norm=(xp, inv, dz, dout))
+    # masked run on poisoned inputs
+    nan = float("nan")
+    nei_p, x_p = nei.clone(), x.clone()
+    nei_p[~keep] = nan
+    x_p[~keep] = nan
+    xp2, inv2 = torch.full((n, dout), 7.0, device=DEV), torch.full((n,), 7.0, device=DEV)
+    NG.dense_forward(nei_p, x_p, w1p, w2p, xp2, inv2, None, 0, mask)
+    assert torch.equal(xp2[keep], xp[keep]) and torch.equal(inv2[keep], inv[keep])
+    assert bool((xp2[~keep] == 7.0).all()) and bool((inv2[~keep] == 7.0).all())
+    up_p, dz_p, xp_p = up.clone(), dz.clone(), xp.clone()
+    up_p[~keep] = nan
+    dz_p[~dzf.bool()] = nan                                   # must not be read where dz_flags is 0
+    xp_p[~dzf.bool()] = nan
+    got = NG.dense_backward(up_p, nei_p, x_p, w1p, w2p, norm=(xp_p, inv, dz_p, dout), row_mask=mask, dz_flags=dzf)
+    for a, b in zip(got[:2], ref[:2]):
+        assert torch.equal(a[keep], b[keep])
+    for a, b in zip(got[2:], ref[2:]):                        # weight gradients: same rows contribute, same fold order
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-4)
+        assert bool(torch.isfinite(a).all())
