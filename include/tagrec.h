@@ -312,6 +312,11 @@ int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
 int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* v, int64_t n,
                           float lr, float b1, float b2, float eps, int64_t* step_dev, float* coef_dev, void* stream);
 
+/* out = srcs[0] + ... + srcs[n_srcs - 1] (1 <= n_srcs <= 8, n floats each, summed left to right) in one pass: the
+ * gradient of a table that several consumers read (what autograd's pairwise accumulation does in 3 passes per extra
+ * gradient).  `srcs` is a HOST array of device pointers; `out` may alias a source. */
+int tagrec_sum_n_f32(float* out, const float* const* srcs, int n_srcs, int64_t n, void* stream);
+
 /* ---- NGCF layer, dense half (ngcf.py:77-86), exact-fp32 MFMA ------------------------------------------
  * Given N = A @ X (tagrec_spmm_f32) and W1p = W1 + b1, W2p = W2 + b2 (row-major [Din, Dout]; the
  * reference adds the 1 x Dout bias to the weight matrix, ngcf.py:78,82):

@@ -756,3 +756,66 @@ extern "C" int tagrec_row_flags_f32(const float* X, int64_t n_rows, int D, uint8
   }
   return count_flags(row_flags, n_rows, count, s);
 }
+
+// ---- out = s_0 + s_1 + ... + s_{k-1} in ONE pass (k <= 8), summed left to right --------------------------------------
+// A table read by several consumers (TGCN: the Q projection, two neighbour attentions, the node's own slot) receives
+// one gradient per consumer; autograd adds them pairwise -- three passes over the table per extra gradient.  Here the
+// k gradients are read once and the sum written once.  `out` may alias any source (element-wise).
+namespace tagrec {
+typedef float sum_f4 __attribute__((ext_vector_type(4)));
+struct SumSrcs { const sum_f4* p[8]; };
+template <int K>
+__global__ __launch_bounds__(256) void sum_n_kernel(SumSrcs s, sum_f4* __restrict__ out, int64_t n4) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    sum_f4 a = __builtin_nontemporal_load(s.p[0] + i);
+#pragma unroll
+    for (int k = 1; k < K; ++k) a += __builtin_nontemporal_load(s.p[k] + i);
+    out[i] = a;
+  }
+}
+__global__ void sum_n_tail_kernel(SumSrcs s, int k, float* __restrict__ out, int64_t lo, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = lo + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float a = reinterpret_cast<const float*>(s.p[0])[i];
+    for (int j = 1; j < k; ++j) a += reinterpret_cast<const float*>(s.p[j])[i];
+    out[i] = a;
+  }
+}
+}  // namespace tagrec
+
+extern "C" int tagrec_sum_n_f32(float* out, const float* const* srcs, int n_srcs, int64_t n, void* stream) {
+  TAGREC_REQUIRE(out != nullptr && srcs != nullptr && n_srcs >= 1 && n_srcs <= 8 && n >= 0, "sum_n: 1 .. 8 sources expected");
+  tagrec::SumSrcs s{};
+  bool al = aligned16(out);
+  for (int k = 0; k < n_srcs; ++k) {
+    TAGREC_REQUIRE(srcs[k] != nullptr, "sum_n: null source");
+    s.p[k] = reinterpret_cast<const tagrec::sum_f4*>(srcs[k]);
+    al = al && aligned16(srcs[k]);
+  }
+  if (n == 0) return TAGREC_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n4 = al ? n / 4 : 0;
+  if (n4 > 0) {
+    const int64_t want = (n4 + 255) / 256;
+    const unsigned blocks = static_cast<unsigned>(want < 8192 ? want : 8192);
+    tagrec::sum_f4* o = reinterpret_cast<tagrec::sum_f4*>(out);
+    switch (n_srcs) {
+      case 1: tagrec::sum_n_kernel<1><<<blocks, 256, 0, st>>>(s, o, n4); break;
+      case 2: tagrec::sum_n_kernel<2><<<blocks, 256, 0, st>>>(s, o, n4); break;
+      case 3: tagrec::sum_n_kernel<3><<<blocks, 256, 0, st>>>(s, o, n4); break;
+      case 4: tagrec::sum_n_kernel<4><<<blocks, 256, 0, st>>>(s, o, n4); break;
+      case 5: tagrec::sum_n_kernel<5><<<blocks, 256, 0, st>>>(s, o, n4); break;
+      case 6: tagrec::sum_n_kernel<6><<<blocks, 256, 0, st>>>(s, o, n4); break;
+      case 7: tagrec::sum_n_kernel<7><<<blocks, 256, 0, st>>>(s, o, n4); break;
+      default: tagrec::sum_n_kernel<8><<<blocks, 256, 0, st>>>(s, o, n4); break;
+    }
+    TAGREC_LAUNCH_CHECK();
+  }
+  if (n4 * 4 < n) {                                        // unaligned operands or the last n % 4 elements
+    const int64_t want = (n - n4 * 4 + 255) / 256;
+    tagrec::sum_n_tail_kernel<<<static_cast<unsigned>(want < 4096 ? want : 4096), 256, 0, st>>>(s, n_srcs, out, n4 * 4, n);
+    TAGREC_LAUNCH_CHECK();
+  }
+  return TAGREC_OK;
+}

@@ -97,6 +97,72 @@ def _pull_compact(idxc, attnc, doc, dh, n_dst):
     return S.spmm(dh), G.spmm(doc)
 
 
+def _active_rows(d_out):
+    """Indices of the rows of d_out [n, D] that hold a non-zero (one pass: tagrec_row_flags_f32 + nonzero)."""
+    n, D = d_out.shape
+    flags = torch.empty(n, dtype=torch.uint8, device=d_out.device)
+    count = torch.zeros(1, dtype=torch.int32, device=d_out.device)
+    _lib.check(_lib.load().tagrec_row_flags_f32(_lib.ptr(d_out), n, D, _lib.ptr(flags), _lib.ptr(count), _lib.stream_ptr()),
+               "row_flags")
+    return torch.nonzero(flags).flatten()
+
+
+def sum_n(tensors, out=None):
+    """tensors[0] + tensors[1] + ... (same shape, contiguous, at most 8 per launch) in one pass over memory."""
+    tensors = [t.contiguous() for t in tensors]
+    if out is None:
+        out = torch.empty_like(tensors[0])
+    lib = _lib.load()
+    first = True
+    while tensors:
+        part, tensors = tensors[:8 if first else 7], tensors[8 if first else 7:]
+        if not first:
+            part = [out] + part
+        arr = (_lib.c_void_p * len(part))(*[t.data_ptr() for t in part])
+        _lib.check(lib.tagrec_sum_n_f32(_lib.ptr(out), arr, len(part), out.numel(), _lib.stream_ptr()), "sum_n")
+        first = False
+    return out
+
+
+class _Fan(torch.autograd.Function):
+    """A table with several readers: n_dense aliases of x (the Q projection, the neighbour attentions that gather from it,
+    the nodes' own slot) and x[rows_i] for every index list.  Backward = ONE n-way sum of the dense gradients plus an
+    index_add of the row-subset gradients, in place of autograd's pairwise accumulation (three passes over the table per
+    extra dense gradient; a zero fill and three passes per row subset)."""
+
+    @staticmethod
+    def forward(ctx, x, n_dense, *rows):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*rows)
+        ctx.n_dense, ctx.shape = n_dense, x.shape
+        return tuple([x.view_as(x) for _ in range(n_dense)] + [x.index_select(0, r) for r in rows])
+
+    @staticmethod
+    def backward(ctx, *gs):
+        rows = ctx.saved_tensors
+        dense = [g for g in gs[:ctx.n_dense] if g is not None]
+        sub = [(r, g) for r, g in zip(rows, gs[ctx.n_dense:]) if g is not None and g.shape[0] > 0]
+        if not dense and not sub:
+            return (None, None) + (None,) * len(rows)
+        if len(dense) == 1 and not sub:
+            out = dense[0]
+        elif dense:
+            out = sum_n(dense)
+        else:
+            out = torch.zeros(ctx.shape, dtype=sub[0][1].dtype, device=sub[0][1].device)
+        for r, g in sub:
+            out.index_add_(0, r, g)
+        return (out, None) + (None,) * len(rows)
+
+
+def fan(x, n_dense, *rows):
+    """(aliases, row subsets) of x; plain indexing when nothing needs a gradient."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return [x] * n_dense, [x.index_select(0, r) for r in rows]
+    outs = _Fan.apply(x, n_dense, *rows)
+    return list(outs[:n_dense]), list(outs[n_dense:])
+
+
 class _NbrAttention(torch.autograd.Function):
     """(P, Q, WT, v, Ej) + static index tables -> attended neighbour embedding [n, D]."""
 
@@ -129,7 +195,7 @@ class _NbrAttention(torch.autograd.Function):
         # Row-local in d_out like the dense block: nodes whose output gradient is zero (all but the batch rows / their
         # sampled neighbours) are dropped, and the few remaining (node, neighbour) pairs use the scatter form.
         if n >= _SPARSE_MIN_ROWS and not torch.cuda.is_current_stream_capturing():      # (needs a host read)
-            active = torch.nonzero(d_out.abs().amax(dim=1) > 0).flatten()
+            active = _active_rows(d_out)
             if active.numel() * 2 < n:
                 nc = active.numel()
                 dPc = torch.empty(nc, A, dtype=torch.float32, device=P.device)
@@ -254,7 +320,7 @@ class _FusedDense(torch.autograd.Function):
         # they contribute 0) and the results scattered back.  One host read of the row count per call.
         active = None
         if n >= _SPARSE_MIN_ROWS and not torch.cuda.is_current_stream_capturing():      # (needs a host read)
-            nz = torch.nonzero(d_out.abs().amax(dim=1) > 0).flatten()
+            nz = _active_rows(d_out)
             if nz.numel() * 2 < n:
                 active = nz
         if active is None:
@@ -375,25 +441,42 @@ class _Layer(nn.Module):
         return outs
 
 
-    def forward_rows(self, emb, ewp, nbr, rows_out, rows_in, pos_in, chunk_rows, use_checkpoint, fused=True, inv=None):
+    def forward_rows(self, emb, ewp, nbr, rows_out, rows_in, pos_in, chunk_rows, use_checkpoint, fused=True, inv=None,
+                     extra_rows=None):
         """`forward` restricted to the rows a mini-batch's loss depends on, on COMPACT tables.  emb[t]: the input table
         of type t -- all rows when rows_in[t] is None, otherwise only the rows rows_in[t] (in that order), with
         pos_in[t][id + 1] = 1 + position of node id in it (int32, 0 for the pad id).  rows_out[t]: rows whose outputs
         are wanted (None = every row; otherwise a subset of rows_in[t] that also holds every neighbour of those rows).
-        Returns {type: outputs of those rows, in that order}."""
+        extra_rows[t] (optional): positions in emb[t] the caller wants as well (the batch rows the loss reads).
+        Returns ({type: outputs of those rows, in that order}, {type: emb[t][extra_rows[t]]}).
+        Every table is read through `fan`, so its gradient is formed by one n-way sum."""
         D = self.in_features
         inv = inv if inv is not None else [None] * 6
         others = {"user": ("item", "tag"), "item": ("user", "tag"), "tag": ("user", "item")}
         A = self.U.shape[1]
         pick = lambda x, rows: x if rows is None else x.index_select(0, rows)
-        Q, P, selfv = {}, {}, {}
+        Q, P, selfv, nb_alias, extras = {}, {}, {}, {}, {}
         for t, (n1, n2) in others.items():
-            Q[t] = _tall_mm(emb[t], self.atten1[t].W_2)     # read wherever t is the NEIGHBOUR type: rows_in[t]
-            if rows_out[t] is None or rows_in[t] is None:
-                selfv[t] = pick(emb[t], rows_out[t])
+            if rows_out[t] is None:
+                self_idx = None
+            elif rows_in[t] is None:
+                self_idx = rows_out[t]
             else:
-                selfv[t] = emb[t].index_select(0, pos_in[t].index_select(0, rows_out[t] + 1).long() - 1)
-            y = _tall_mm(selfv[t], torch.cat([self.atten1[n1].W_1[:D], self.atten1[n2].W_1[:D]], dim=1))
+                self_idx = pos_in[t].index_select(0, rows_out[t] + 1).long() - 1
+            sels = [i for i in (self_idx, extra_rows.get(t) if extra_rows else None) if i is not None]
+            # dense readers: the Q projection, the two relations whose NEIGHBOUR type is t, (every row's own slot: two readers)
+            al, sub = fan(emb[t], 3 + (2 if self_idx is None else 0), *sels)
+            Q[t] = _tall_mm(al[0], self.atten1[t].W_2)       # read wherever t is the NEIGHBOUR type: rows_in[t]
+            nb_alias[t] = [al[1], al[2]]
+            if self_idx is None:
+                s_p, s_d = al[3], al[4]
+            else:
+                (s_p, s_d), _ = fan(sub[0], 2)
+                sub = sub[1:]
+            if sub:
+                extras[t] = sub[0]
+            selfv[t] = s_d
+            y = _tall_mm(s_p, torch.cat([self.atten1[n1].W_1[:D], self.atten1[n2].W_1[:D]], dim=1))
             P[(t, n1)] = y[:, :A] + self.atten1[n1].b
             P[(t, n2)] = y[:, A:] + self.atten1[n2].b
         WT = {t: ewp @ self.atten1[t].W_1[D:] for t in emb}
@@ -406,7 +489,7 @@ class _Layer(nn.Module):
             idx, widx = pick(nbr[r][0], rows), pick(nbr[r][1], rows)
             if rows_in[nb] is not None:                      # neighbour ids -> positions in the compact table
                 idx = pos_in[nb].index_select(0, idx.flatten().long()).reshape(idx.shape)
-            return neighbour_attention(P[(src, nb)].contiguous(), Q[nb], WT[nb], a.v.reshape(-1), emb[nb], idx, widx,
+            return neighbour_attention(P[(src, nb)].contiguous(), Q[nb], WT[nb], a.v.reshape(-1), nb_alias[nb].pop(), idx, widx,
                                        inv[r] if rows is None and rows_in[nb] is None else None)
 
         eu_i, eu_t = att("user", "item", 0), att("user", "tag", 1)
@@ -414,7 +497,7 @@ class _Layer(nn.Module):
         et_u, et_i = att("tag", "user", 4), att("tag", "item", 5)
         trips = {"user": (selfv["user"], eu_i, eu_t), "item": (ei_u, selfv["item"], ei_t), "tag": (et_u, et_i, selfv["tag"])}
         return {t: (self.dense(trip, chunk_rows, use_checkpoint, fused) if trip[0].shape[0] > 0
-                    else trip[0].new_zeros(0, self.Wf.shape[1])) for t, trip in trips.items()}
+                    else trip[0].new_zeros(0, self.Wf.shape[1])) for t, trip in trips.items()}, extras
 
 
 def neighbor_tables(data, neighbor_k, seed=0):
@@ -635,14 +718,17 @@ class TGCN(nn.Module):
         ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])
         emb = {"user": self.embed["user"], "item": self.embed["item"], "tag": self.embed["tag"]}
         top = need[len(self.layer)]
-        at_top = lambda z, rows, pos, t: z.index_select(0, top[t] if rows is None else pos.index_select(0, top[t] + 1).long() - 1)
-        cat = {t: [emb[t].index_select(0, top[t])] for t in ("user", "item")}
+        cat = {"user": [], "item": []}
         rows_in = {t: None for t in emb}
         pos_in = {t: None for t in emb}
+        extra = {t: top[t] for t in cat}                      # positions in the current tables of the rows the loss reads
         for i, layer in enumerate(self.layer.values()):
             rows_out = need[i + 1]
-            outs = layer.forward_rows(emb, ewp, self.nbr, rows_out, rows_in, pos_in, self.chunk_rows, self.use_checkpoint,
-                                      self.fused_dense, self.inv)
+            outs, picked = layer.forward_rows(emb, ewp, self.nbr, rows_out, rows_in, pos_in, self.chunk_rows, self.use_checkpoint,
+                                              self.fused_dense, self.inv, extra)
+            for t in cat:                                       # the loss reads the normalised rows of the batch only
+                pt = picked[t]
+                cat[t].append(pt if i == 0 or not pt.shape[0] else H.normalize_rows(pt))
             p = self.message_drop_list[i]
             nxt, pos_out = {}, {}
             for t, o in outs.items():
@@ -653,10 +739,11 @@ class TGCN(nn.Module):
                 if rows_out[t] is not None:
                     pos_out[t] = torch.zeros(sizes[t] + 1, dtype=torch.int32, device=self.device)
                     pos_out[t][rows_out[t] + 1] = torch.arange(1, rows_out[t].numel() + 1, dtype=torch.int32, device=self.device)
-                if t in cat:                                    # the loss reads the normalised rows of the batch only
-                    ot = at_top(o, rows_out[t], pos_out[t], t)
-                    cat[t].append(H.normalize_rows(ot) if ot.shape[0] else ot)
+            extra = {t: (top[t] if rows_out[t] is None else pos_out[t].index_select(0, top[t] + 1).long() - 1) for t in cat}
             emb, rows_in, pos_in = nxt, rows_out, pos_out
+        for t in cat:
+            ot = emb[t].index_select(0, extra[t])
+            cat[t].append(H.normalize_rows(ot) if ot.shape[0] else ot)
         trip = torch.stack([torch.searchsorted(top["user"], batch[:, 0].contiguous()),
                             torch.searchsorted(top["item"], batch[:, 1].contiguous()),
                             torch.searchsorted(top["item"], batch[:, 2].contiguous())], dim=1)

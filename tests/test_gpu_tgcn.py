@@ -503,3 +503,32 @@ def test_tall_projection_weight_gradient_by_slabs():
     ref_x = dY.double() @ W.detach().double().t()
     assert float((gw.double() - ref_w).abs().max()) <= 1e-5 * float(ref_w.abs().max())
     assert float((gx.double() - ref_x).abs().max()) <= 1e-5 * float(ref_x.abs().max())
+
+
+def test_sum_n_and_table_fan_out():
+    """`sum_n` (one-pass sum of up to 8 tensors per launch, left to right) and `fan` (a table read by several consumers:
+    aliases + row subsets whose gradients are folded by one n-way sum + index_add) against plain autograd."""
+    torch.manual_seed(1)
+    for shape in ((1003, 7), (4096, 128), (5,)):
+        ts = [torch.randn(*shape, device=DEV) for _ in range(11)]
+        ref = ts[0].clone()
+        for t in ts[1:]:
+            ref = ref + t
+        assert torch.equal(TG.sum_n(ts[:3]), ts[0] + ts[1] + ts[2])          # same order of additions: bit-identical
+        np.testing.assert_allclose(TG.sum_n(ts).cpu().numpy(), ref.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    x = torch.randn(300, 16, device=DEV, requires_grad=True)
+    r1 = torch.randint(0, 300, (500,), device=DEV)
+    r2 = torch.tensor([299, 0, 0], device=DEV)
+    w = torch.randn(16, 4, device=DEV)
+
+    def loss_of(a, b, c, s1, s2):
+        return (a * a).sum() + (b @ w).sum() + (s1 ** 3).sum() + 2 * s2.sum()   # c: a reader that is never used
+
+    (a, b, c), (s1, s2) = TG.fan(x, 3, r1, r2)
+    loss_of(a, b, c, s1, s2).backward()
+    got, x.grad = x.grad.clone(), None
+    loss_of(x, x, x, x[r1], x[r2]).backward()
+    np.testing.assert_allclose(got.cpu().numpy(), x.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    with torch.no_grad():
+        (a, b), (s1,) = TG.fan(x, 2, r1)
+        assert a.data_ptr() == x.data_ptr() and torch.equal(s1, x[r1])
