@@ -1173,35 +1173,105 @@ __global__ __launch_bounds__(kFuseThreads * NH) void tgcn_fuse_wf_kernel(
       // k-step touches (lanes q = 0..3) fall on disjoint 16-bank ranges.
       constexpr int SN = 8;                                   // nodes per stage
       constexpr int TB = SN * D * 4, GB = SN * DOUT * 4;      // bytes per staged tensor
-      constexpr int STAGE = 3 * TB + 2 * GB + 128;            // T0 T1 T2 | dOut | out | bw (8 x 3 floats, padded)
+      // T0 T1 T2 | dOut | out | bw (8 x 3 floats, padded) | yvec [8, 48] | dfeat [8, 48] | dS [8, 3 A]: the last three
+      // feed the LIGHT products (vector-level rows of dWf, G, dU), which the heavy blocks carry along (see below)
+      constexpr int BWO = 3 * TB + 2 * GB, YVO = BWO + 1024, DFO = YVO + 2048, DSO = DFO + 2048;
+      constexpr int PV = (SN * NF * 4 + 1023) / 1024, PS = (SN * 3 * A * 4 + 1023) / 1024;   // 1 KiB pieces of yvec / dfeat, of dS
+      constexpr int STAGE = DSO + PS * 1024;
+      static_assert(PV * 1024 <= 2048 && SN * NF % 4 == 0, "stage layout");
+      static_assert(D != 128 || DOUT != 128 || STAGE == 28672, "stage size");
       // Node rows come from HBM the first time (eight blocks share a node range, the other seven hit L2): a stage is
       // two k-steps of MFMAs, far shorter than that miss, so THREE stages are kept in flight (four buffers) and the
       // waits are counted -- `s_waitcnt vmcnt(k * CNT)` + a raw s_barrier, never the vmcnt(0) of __syncthreads().
       constexpr int AHEAD = 3, NBUF = AHEAD + 1;
       __shared__ __attribute__((aligned(1024))) char sbuf[NBUF][STAGE];
-      const float* srcT[3] = {T0, T1, T2};
       constexpr int WPB = 4 * NH;
       constexpr int PT = TB / 1024, PG = GB / 1024;           // 1 KiB pieces per tensor
-      constexpr int NPIECE = 3 * PT + 2 * PG + 1;             // + the bw piece
+      constexpr int NMAINP = 3 * PT + 2 * PG + 1;             // + the bw piece
+      constexpr int NPIECE = NMAINP + 2 * PV + PS;            // + yvec, dfeat, dS
       constexpr int CNT = (NPIECE + WPB - 1) / WPB;           // DMA instructions per wave and stage (uniform: see below)
-      auto issue = [&](int64_t node0, int buf) {
+      // LIGHT products, carried along: the vector-level rows of dWf (yvec^T g), G (dfeat^T e_j) and dU (t_j^T dS_j) are 7 %
+      // of the flops but were 28 % of the blocks when they had blocks of their own (load-latency bound: one float per lane
+      // straight from global).  Their accumulator tiles are dealt to the 8 x WPB waves that share a node group -- tile ids
+      // u, u + NW, ..: [0, NTU) dU (three MFMAs per k-step), then the vector rows, then G -- and their operands come out
+      // of the stage the heavy product already has in LDS (+ yvec, dfeat, dS: 6 KB per stage).
+      constexpr int NTU = IB * AB, NTV = FB * OB, NTG = FB * 3 * IB, NT = NTU + NTV + NTG;
+      constexpr int NW = 8 * WPB, MAXT = (NT + NW - 1) / NW;
+      const int u = kg * WPB + __builtin_amdgcn_readfirstlane(wave);    // wave-uniform, in a scalar register
+      // per tile: kind (0 dU, 1 vector rows, 2 G, 3 none), the relation j of a G tile, and the lane's float offsets of its
+      // A / B operands inside a stage for k-step 0 (a k-step later = 4 node rows further)
+      f32x4 lacc[MAXT];
+      int lkind[MAXT], lj[MAXT], la[MAXT], lb[MAXT];
+      auto rot = [&](int blk, int W) { return q * W + 4 * ((4 * blk + (m >> 2) + 4 * q) & (W / 4 - 1)) + (m & 3); };
+#pragma unroll
+      for (int it = 0; it < MAXT; ++it) {
+        lacc[it] = zero4();
+        const int tile = u + it * NW;
+        lkind[it] = 3; lj[it] = 0; la[it] = 0; lb[it] = 0;
+        if (tile < NTU) {
+          lkind[it] = 0;
+          la[it] = rot(tile / AB, D);                                  // t_j row block db (A operand, rows = d)
+          lb[it] = q * (3 * A) + (tile % AB) * 16 + m;                 // dS_j block ab (B operand, cols = a)
+        } else if (tile < NTU + NTV) {
+          const int t = tile - NTU;
+          lkind[it] = 1;
+          la[it] = q * NF + (t / OB) * 16 + m;                         // yvec block fb
+          lb[it] = rot(t % OB, DOUT);                                  // masked dOut block ob
+        } else if (tile < NT) {
+          const int t = tile - NTU - NTV;
+          lkind[it] = 2;
+          lj[it] = (t / IB) % 3;
+          la[it] = q * NF + (t / (3 * IB)) * 16 + m;                   // dfeat block fb
+          lb[it] = rot(t % IB, D);                                     // e_j block db
+        }
+      }
+      const int64_t n_stage = (hi - lo + SN - 1) / SN;
+      // iterations st = -AHEAD .. -1 only issue (stages 0 .. AHEAD-1); the DMA issue is written once, inline -- as a
+      // lambda with two call sites its captures ended up in scratch memory, and a scratch load's wait is a vmcnt(0)
+      for (int64_t st = -AHEAD; st < n_stage; ++st) {
+        if (st >= 0) {
+          const int64_t after = n_stage - 1 - st < AHEAD - 1 ? n_stage - 1 - st : AHEAD - 1;   // stages in flight beyond st
+          if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CNT) : "memory");
+          else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();                                // stage st is in LDS for everyone; buffer (st-1) % NBUF is free
+          asm volatile("" ::: "memory");
+        }
+        if (st + AHEAD < n_stage) {
+          const int64_t node0 = lo + (st + AHEAD) * SN;
+          const int buf = static_cast<int>((st + AHEAD) % NBUF);
         // piece ids: [0, 3 PT) rows of T0..T2, then PG of dOut, PG of out, last = bw.  Wave w takes ids w, w + WPB, ..;
         // a wave whose last slot has no piece repeats its previous one, so that every wave issues exactly CNT.
 #pragma unroll
         for (int j = 0; j < CNT; ++j) {
           int id = wave + j * WPB;
           if (id >= NPIECE) id -= WPB;
-          if (id == NPIECE - 1) {                               // bw: 24 consecutive floats of [n, 3]
+          if (id == NMAINP - 1) {                               // bw: 24 consecutive floats of [n, 3]
             int64_t e = node0 * 3 + (lane < 3 * SN ? lane : 0);
             if (e >= n * 3) e = n * 3 - 1;
             if (lane < 3 * SN)
               __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bw + e),
-                                               (__attribute__((address_space(3))) void*)&sbuf[buf][3 * TB + 2 * GB], 4, 0, 0);
+                                               (__attribute__((address_space(3))) void*)&sbuf[buf][BWO], 4, 0, 0);
+            continue;
+          }
+          if (id >= NMAINP) {                                   // yvec / dfeat / dS: the stage's 8 rows are one contiguous run
+            const int x = id - NMAINP;
+            const float* src = x < PV ? yvec : (x < 2 * PV ? dfeat : dS);
+            const int rf = x < 2 * PV ? NF : 3 * A;               // floats per node row
+            const int piece = x < PV ? x : (x < 2 * PV ? x - PV : x - 2 * PV);
+            const int off = x < PV ? YVO : (x < 2 * PV ? DFO : DSO);
+            const int unit = piece * 64 + lane;                   // 16-byte unit inside the run
+            int64_t e = node0 * rf + unit * 4;
+            if (e > n * rf - 4) e = n * rf - 4;                   // clamped; rows past n are masked out when read
+            if (unit * 4 < SN * rf)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e),
+                                               (__attribute__((address_space(3))) void*)&sbuf[buf][off + piece * 1024], 16, 0, 0);
             continue;
           }
           const bool is_t = id < 3 * PT;
           const int gi = is_t ? 0 : (id - 3 * PT) / PG;                                  // 0: dOut, 1: out
-          const float* base = is_t ? srcT[id / PT] : (gi == 0 ? dOut : outv);
+          const int ti = id / PT;                                                          // (selects, not a pointer table in scratch)
+          const float* base = is_t ? (ti == 0 ? T0 : (ti == 1 ? T1 : T2)) : (gi == 0 ? dOut : outv);
           const int W = is_t ? D : DOUT;
           const int piece = is_t ? id % PT : (id - 3 * PT) % PG;
           const int off_bytes = is_t ? (id / PT) * TB : 3 * TB + gi * GB;
@@ -1214,24 +1284,14 @@ __global__ __launch_bounds__(kFuseThreads * NH) void tgcn_fuse_wf_kernel(
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + node * W + u * 4),
                                            (__attribute__((address_space(3))) void*)&sbuf[buf][off_bytes + piece * 1024], 16, 0, 0);
         }
-      };
-      const int64_t n_stage = (hi - lo + SN - 1) / SN;
-      for (int k = 0; k < AHEAD; ++k)
-        if (k < n_stage) issue(lo + k * SN, k);
-      for (int64_t st = 0; st < n_stage; ++st) {
-        const int64_t after = n_stage - 1 - st < AHEAD - 1 ? n_stage - 1 - st : AHEAD - 1;   // stages in flight beyond st
-        if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CNT) : "memory");
-        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                  // stage st is in LDS for everyone; buffer (st-1) % NBUF is free
-        asm volatile("" ::: "memory");
-        if (st + AHEAD < n_stage) issue(lo + (st + AHEAD) * SN, static_cast<int>((st + AHEAD) % NBUF));
+        }
+        if (st < 0) continue;
         const char* sb = sbuf[st % NBUF];
 #pragma unroll
         for (int ks = 0; ks < SN / 4; ++ks) {
           const int nd = ks * 4 + q;                                   // node slot of this lane's k index
           const bool ok = lo + st * SN + nd < hi;
-          const float* bwp = reinterpret_cast<const float*>(sb + 3 * TB + 2 * GB) + nd * 3;
+          const float* bwp = reinterpret_cast<const float*>(sb + BWO) + nd * 3;
           const float b0 = bwp[0], b1 = bwp[1], b2 = bwp[2];
           float y[IBH], g[OB];
 #pragma unroll
@@ -1254,6 +1314,51 @@ __global__ __launch_bounds__(kFuseThreads * NH) void tgcn_fuse_wf_kernel(
           for (int i = 0; i < IBH; ++i)
 #pragma unroll
             for (int o = 0; o < OB; ++o) acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[i], g[o], acc[i][o], 0, 0, 0);
+#pragma unroll
+          for (int it = 0; it < MAXT; ++it) {                           // this wave's light tiles (scalar branches)
+            const int ao = la[it] + ks * 4 * (lkind[it] == 0 ? D : NF);
+            if (lkind[it] == 0) {
+              const int bo = lb[it] + ks * 4 * 3 * A;
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                const float tv = reinterpret_cast<const float*>(sb + j * TB)[ao];
+                const float dsv = reinterpret_cast<const float*>(sb + DSO)[bo + j * A];
+                lacc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? tv : 0.f, dsv, lacc[it], 0, 0, 0);
+              }
+            } else if (lkind[it] == 1) {
+              const int bo = lb[it] + ks * 4 * DOUT;
+              const float yv = reinterpret_cast<const float*>(sb + YVO)[ao];
+              const float go = reinterpret_cast<const float*>(sb + 3 * TB)[bo];
+              const float ov = reinterpret_cast<const float*>(sb + 3 * TB + GB)[bo];
+              lacc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, (ok && ov > 0.f) ? go : 0.f, lacc[it], 0, 0, 0);
+            } else if (lkind[it] == 2) {
+              const int bo = lb[it] + ks * 4 * D;
+              const float df = reinterpret_cast<const float*>(sb + DFO)[ao];
+              const float e = reinterpret_cast<const float*>(sb + lj[it] * TB)[bo] * bwp[lj[it]];
+              lacc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? df : 0.f, e, lacc[it], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // the light tiles' partial sums: [vector-level rows of dWf | G | dU] of this node group
+      float* sdst = part_small + ng * SMALL;
+#pragma unroll
+      for (int it = 0; it < MAXT; ++it) {
+        const int tile = u + it * NW;
+        if (tile < NTU) {
+          const int db = tile / AB, ab = tile % AB;
+          float* udst = sdst + static_cast<int64_t>(NF) * DOUT + static_cast<int64_t>(NF) * 3 * D;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) udst[static_cast<int64_t>(db * 16 + q * 4 + v) * A + ab * 16 + m] = lacc[it][v];
+        } else if (tile < NTU + NTV) {
+          const int t = tile - NTU, fb = t / OB, ob = t % OB;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) sdst[static_cast<int64_t>(fb * 16 + q * 4 + v) * DOUT + ob * 16 + m] = lacc[it][v];
+        } else if (tile < NT) {
+          const int t = tile - NTU - NTV, fb = t / (3 * IB), j = (t / IB) % 3, db = t % IB;
+          float* gdst = sdst + static_cast<int64_t>(NF) * DOUT;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) gdst[(static_cast<int64_t>(fb * 16 + q * 4 + v) * 3 + j) * D + db * 16 + m] = lacc[it][v];
         }
       }
     } else {
@@ -1336,8 +1441,10 @@ __global__ __launch_bounds__(kFuseThreads * NH) void tgcn_fuse_wf_kernel(
   }
 }
 
-constexpr int kWfGroups = 23;        // 8 x 23 heavy blocks + 2 x 36 light ones = 256: one block per CU; the split
+constexpr int kWfGroups = 23;        // unstaged shapes: 8 x 23 heavy blocks + 2 x 36 light ones = 256: one block per CU; the split
 constexpr int kWfSmallGroups = 36;   // equalises their measured times (heavy-only 13.4 ms at 26 groups, light-only 11.3 ms at 48; 1 M nodes, D = 128)
+constexpr int kWfMergedGroups = 32;  // staged shapes (D, Dout in {64, 128}): 8 x 32 blocks, light products carried along
+static_assert(kWfMergedGroups <= kWfSmallGroups && kWfMergedGroups >= kWfGroups, "workspace layout");
 
 template <int D, int DOUT>
 int launch_fuse_wf(const float* T0, const float* T1, const float* T2, const float* bw, const float* yvec, const float* wb,
@@ -1352,9 +1459,12 @@ int launch_fuse_wf(const float* T0, const float* T1, const float* T2, const floa
     *per = ((n + groups - 1) / groups + 7) / 8 * 8;
     return (n + *per - 1) / *per;
   };
+  // staged shapes: the heavy blocks carry the light products along (no light blocks), 8 x 32 blocks = one per CU
+  constexpr bool kMerged = (D == 64 || D == 128) && (DOUT == 64 || DOUT == 128);
   int64_t per = 0, per_small = 0;
-  const int64_t groups = split(kWfGroups, &per), small_groups = split(kWfSmallGroups, &per_small);
-  float* ws_small = ws + static_cast<int64_t>(kWfGroups) * KBIT;
+  const int64_t groups = split(kMerged ? kWfMergedGroups : kWfGroups, &per);
+  const int64_t small_groups = kMerged ? 0 : split(kWfSmallGroups, &per_small);
+  float* ws_small = ws + static_cast<int64_t>(kWfMergedGroups) * KBIT;
   constexpr int NH = (D == 128 && DOUT == 128) ? 2 : 1;
   tgcn_fuse_wf_kernel<D, DOUT, NH><<<static_cast<unsigned>(8 * groups + 2 * small_groups), kFuseThreads * NH, 0, s>>>(
       T0, T1, T2, bw, yvec, wb, outv, dOut, dfeat, dS, n, per, static_cast<int>(groups), per_small, ws, ws_small);
@@ -1362,7 +1472,7 @@ int launch_fuse_wf(const float* T0, const float* T1, const float* T2, const floa
   // one contiguous result [dWf | G | dU] (the caller hands a buffer of that size): bit-level rows, then the rest
   fuse_fold_kernel<<<static_cast<unsigned>((KBIT + 255) / 256), 256, 0, s>>>(ws, static_cast<int>(groups), static_cast<int>(KBIT), dWf);
   TAGREC_LAUNCH_CHECK();
-  fuse_fold_kernel<<<static_cast<unsigned>((SMALL + 255) / 256), 256, 0, s>>>(ws_small, static_cast<int>(small_groups),
+  fuse_fold_kernel<<<static_cast<unsigned>((SMALL + 255) / 256), 256, 0, s>>>(ws_small, static_cast<int>(kMerged ? groups : small_groups),
                                                                             static_cast<int>(SMALL), dWf + KBIT);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
@@ -1436,7 +1546,7 @@ extern "C" int64_t tagrec_tgcn_fuse_wf_result(int D, int Dout) {      // floats 
 
 extern "C" int64_t tagrec_tgcn_fuse_wf_workspace(int D, int Dout) {
   const int64_t kbit = static_cast<int64_t>(kBitC) * D * Dout;
-  return static_cast<int64_t>(kWfGroups) * kbit + static_cast<int64_t>(kWfSmallGroups) * (tagrec_tgcn_fuse_wf_result(D, Dout) - kbit);
+  return static_cast<int64_t>(kWfMergedGroups) * kbit + static_cast<int64_t>(kWfSmallGroups) * (tagrec_tgcn_fuse_wf_result(D, Dout) - kbit);
 }
 
 extern "C" int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, const float* bw,
