@@ -1203,10 +1203,17 @@ __global__ __launch_bounds__(kFuseThreads * NH) void tgcn_fuse_wf_kernel(
       f32x4 lacc[MAXT];
       int lkind[MAXT], lj[MAXT], la[MAXT], lb[MAXT];
       auto rot = [&](int blk, int W) { return q * W + 4 * ((4 * blk + (m >> 2) + 4 * q) & (W / 4 - 1)) + (m & 3); };
+      // a dU tile costs three MFMAs per k-step, the others one: where the other tiles fit on the remaining waves, a wave
+      // with a dU tile carries nothing else (D = Dout = 128: 16 waves x 3 and 48 waves x 2 instead of up to 4)
+      constexpr bool kSoloU = NTU <= NW && (NT - NTU) <= MAXT * (NW - NTU);
+      auto tile_of = [&](int it) {
+        if constexpr (kSoloU) return u < NTU ? (it == 0 ? u : NT) : NTU + it * (NW - NTU) + (u - NTU);
+        else return u + it * NW;
+      };
 #pragma unroll
       for (int it = 0; it < MAXT; ++it) {
         lacc[it] = zero4();
-        const int tile = u + it * NW;
+        const int tile = tile_of(it);
         lkind[it] = 3; lj[it] = 0; la[it] = 0; lb[it] = 0;
         if (tile < NTU) {
           lkind[it] = 0;
@@ -1344,7 +1351,7 @@ __global__ __launch_bounds__(kFuseThreads * NH) void tgcn_fuse_wf_kernel(
       float* sdst = part_small + ng * SMALL;
 #pragma unroll
       for (int it = 0; it < MAXT; ++it) {
-        const int tile = u + it * NW;
+        const int tile = tile_of(it);
         if (tile < NTU) {
           const int db = tile / AB, ab = tile % AB;
           float* udst = sdst + static_cast<int64_t>(NF) * DOUT + static_cast<int64_t>(NF) * 3 * D;
