@@ -747,12 +747,14 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
   constexpr int DS = D / 4, HS = DS / 2, OS = DOUT / 4, IB = D / 16, HB = IB / 2, AB = A / 16, AS = A / 4;
   constexpr int NSM = 3 * kBitC + 2 * A;             // dwb | dq | dp
   __shared__ float sh[NSM];
+  __shared__ float sh_wb4[3 * kBitC * 4];            // dwb partials, one slot per lane row q: no same-address LDS atomics
   constexpr int NB = 2;
   constexpr int RP = 256 / DOUT, PPW = (NB * 16 / RP) / 4, CHUNK = NB * 16 * DOUT * 4;
   constexpr int NBUF = 3, CPH = HB / NB, NCH = 2 * kBitC * CPH;   // chunks per (filter, half); chunks per tile group
   static_assert(HB % NB == 0 && CPH >= 1 && NCH >= 4, "tgcn_fuse_bwd2: unsupported shape");
   __shared__ __attribute__((aligned(1024))) char wbuf[NBUF][CHUNK];
   for (int i = threadIdx.x; i < NSM; i += kFuseThreads) sh[i] = 0.f;
+  for (int i = threadIdx.x; i < 3 * kBitC * 4; i += kFuseThreads) sh_wb4[i] = 0.f;
   __syncthreads();
   float* sh_wb = sh;
   float* sh_q = sh + 3 * kBitC;
@@ -893,9 +895,14 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
             a2 = fmaf(dp_, e3h[2][e], a2);
           }
         }
+        // over the 16 nodes of a lane row by DPP (register speed); the four rows add into their own LDS slots without a
+        // return value (the two cross-row shuffle rounds went through the LDS pipe and stalled the wave once per filter;
+        // four lanes adding into ONE address serialise and cost more than they save)
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
-        if (lane == 0) { atomicAdd(&sh_wb[c * 3], a0); atomicAdd(&sh_wb[c * 3 + 1], a1); atomicAdd(&sh_wb[c * 3 + 2], a2); }
+        for (int m = 1; m < 16; m <<= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+        if (r == 0) {
+          atomicAdd(&sh_wb4[(c * 3) * 4 + q], a0); atomicAdd(&sh_wb4[(c * 3 + 1) * 4 + q], a1); atomicAdd(&sh_wb4[(c * 3 + 2) * 4 + q], a2);
+        }
       }
       // vector-level contribution to the half: de_h[d] += sum_c w[c][a][d] dpre[c]
 #pragma unroll
@@ -1005,6 +1012,9 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
     b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4); b += __shfl_xor(b, 8);
     if (r == 0) { atomicAdd(&sh_q[q * AS + i], a); atomicAdd(&sh_p[q * AS + i], b); }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * kBitC; i += kFuseThreads)
+    sh_wb[i] = (sh_wb4[i * 4] + sh_wb4[i * 4 + 1]) + (sh_wb4[i * 4 + 2] + sh_wb4[i * 4 + 3]);
   __syncthreads();
   float* o = part + static_cast<int64_t>(blockIdx.x) * NSM;
   for (int i = threadIdx.x; i < NSM; i += kFuseThreads) o[i] = sh[i];
