@@ -76,11 +76,11 @@ class HipOps:
         g.spmm_normbwd_sparse(g_in, in_flags, in_count, x_raw, inv, dz, s, out, out_flags, cnt, row_mask=row_mask,
                               dz_flags=dz_flags)
 
-    def last_hop(self, g, g_in, in_flags, in_count, b, s, out, b_flags=None):
-        if in_flags is None and b_flags is None:
+    def last_hop(self, g, g_in, in_flags, in_count, b, s, out, b_flags=None, row_mask=None):
+        if in_flags is None and b_flags is None and row_mask is None:
             g.spmm_axpy(g_in, b, s, out)
         else:
-            g.spmm_axpy_sparse(g_in, in_flags, in_count, b, s, out, b_flags=b_flags)
+            g.spmm_axpy_sparse(g_in, in_flags, in_count, b, s, out, row_mask=row_mask, b_flags=b_flags)
 
     def rownorm_fwd(self, x):
         n, D = x.shape
@@ -123,13 +123,16 @@ class HipOps:
 
 
     # -- NGCF dense block (csrc/ngcf.hip)
-    def ngcf_dense_fwd(self, nei, x, w1p, w2p, xp, inv, z_slot, ldz):
+    def ngcf_dense_fwd(self, nei, x, w1p, w2p, xp, inv, z_slot, ldz, row_mask=None):
+        """z_slot None: the normalised slot is not written.  row_mask: rows with a zero byte are neither read nor written."""
         from .ngcf import dense_forward
-        dense_forward(nei, x, w1p, w2p, xp, inv, z_slot, ldz)
+        dense_forward(nei, x, w1p, w2p, xp, inv, z_slot, ldz, row_mask)
 
-    def ngcf_dense_bwd(self, dxp, nei, x, w1p, w2p, norm):
+    def ngcf_dense_bwd(self, dxp, nei, x, w1p, w2p, norm, row_mask=None, dz_flags=None):
+        """row_mask: rows with a zero byte are skipped (outputs unwritten there, no share in the weight gradients);
+        dz_flags: rows of the concat gradient with a zero byte are zero and are not read."""
         from .ngcf import dense_backward
-        return dense_backward(dxp, nei, x, w1p, w2p, norm=norm)
+        return dense_backward(dxp, nei, x, w1p, w2p, norm=norm, row_mask=row_mask, dz_flags=dz_flags)
 
     # -- column-sharded tables -------------------------------------------------------------------
     def spmm_axpy(self, g, g_in, b, s, out):
@@ -621,6 +624,156 @@ class ShardedLightGCN(torch.nn.Module):
 
 
 # ====================================================================================== NGCF, row-sharded
+class _ShardedNgcfRestrictedLoss(torch.autograd.Function):
+    """The compact restricted NGCF step (ngcf.restricted_forward / restricted_backward) on a ROW shard.
+
+    Layers below L-1 run on all local rows, layer L-1 (neighbour sum, dense block, weight gradient) on the local part of
+    the batch rows' neighbourhood -- marked through the column slice A[:, rows_g], no exchange --, layer L in push form:
+    every rank sums the part of the batch rows' neighbourhoods it owns and one all-reduce of [T, .] completes the
+    neighbour sums, the batch rows' own vectors and the lower layers' slots of the concatenated output; the top dense
+    block and the loss are then computed redundantly on the T batch rows.  Exchanges per step: X^0 .. X^(L-1) forward,
+    dN^(L-1) (flagged: valid on the masked rows) .. dN^0 backward = 2 L - 1 table exchanges (2 L + 1 in the all-rows
+    step), one small all-reduce each way."""
+
+    @staticmethod
+    def forward(ctx, model, trip, table, *mats):
+        from .ngcf import _wps
+        m, ops, part = model, model.ops, model.part
+        x0 = table.detach()
+        dims = m.dims
+        L, dtot = len(dims) - 1, sum(dims)
+        dev = x0.device
+        wps = _wps([t.detach() for t in mats])
+        B = trip.shape[0]
+        T = 3 * B
+        rows = torch.cat([trip[:, 0], m.n_user + trip[:, 1], m.n_user + trip[:, 2]])      # original node ids, [T]
+        rows_p = part.gathered(rows)
+        slot = torch.nonzero(part.owner(rows) == m.rank).flatten()                       # batch slots this rank owns
+        loc = rows[slot] - m.lo
+        mid = None
+        if L >= 2:
+            mid = torch.zeros(part.per, dtype=torch.uint8, device=dev)
+            ops.mark_cols(m.graph_cols, rows_p, mid)
+            mid.index_fill_(0, loc, 1)
+        saved, x = [], x0
+        for k in range(L - 1):
+            w1p, w2p = wps[k]
+            mk = mid if k == L - 2 else None
+            xf = _Gather(m, x.shape[1], key=("ngcf_fwd", k & 1)).put_all(x).table()
+            nei = torch.empty_like(x)
+            for c in range(part.n_chunks):
+                r = part.chunk_rows(c)
+                ops.spmm_plain(m.graph_chunks[c], xf, nei[r], mk[r] if mk is not None else None)
+            xp = torch.empty(part.per, dims[k + 1], dtype=torch.float32, device=dev)
+            inv = torch.empty(part.per, dtype=torch.float32, device=dev)
+            ops.ngcf_dense_fwd(nei, x, w1p, w2p, xp, inv, None, 0, mk)
+            saved.append((x, nei, xp, inv, w1p, w2p, mk))
+            x = xp
+        # batch rows: [lower slots of the concat output | the rows themselves | partial neighbour sums of the top layer]
+        dlow, dl = sum(dims[:L]), dims[L - 1]
+        buf = torch.zeros(T, dlow + 2 * dl, dtype=torch.float32, device=dev)
+        own = torch.empty(slot.numel(), dlow + dl, dtype=torch.float32, device=dev)
+        own[:, :dims[0]] = x0.index_select(0, loc)
+        off = dims[0]
+        for (_, _, xp, inv, _, _, _) in saved:
+            torch.mul(xp.index_select(0, loc), inv.index_select(0, loc)[:, None], out=own[:, off:off + xp.shape[1]])
+            off += xp.shape[1]
+        own[:, dlow:] = x.index_select(0, loc)
+        buf[:, :dlow + dl].index_copy_(0, slot, own)
+        part_nei = torch.empty(T, dl, dtype=torch.float32, device=dev)
+        ops.spmm_listed(m.graph_cols, rows_p, x, part_nei)
+        buf[:, dlow + dl:] = part_nei
+        m.all_reduce(buf, "batch_rows")
+        xc, nc = buf[:, dlow:dlow + dl].contiguous(), buf[:, dlow + dl:].contiguous()
+        w1p, w2p = wps[L - 1]
+        xpc = torch.empty(T, dims[L], dtype=torch.float32, device=dev)
+        invc = torch.empty(T, dtype=torch.float32, device=dev)
+        out_b = torch.empty(T, dtot, dtype=torch.float32, device=dev)
+        out_b[:, :dlow] = buf[:, :dlow]
+        ops.ngcf_dense_fwd(nc, xc, w1p, w2p, xpc, invc, out_b[:, dlow:], dtot)
+        ar = torch.arange(B, device=dev)
+        ctrip = torch.stack([ar, ar, ar + B], dim=1).contiguous()
+        res, coef = ops.bpr_fwd(out_b[:B], out_b[B:], out_b[:B], out_b[B:], ctrip, H.loss_kind_id(m.loss_func))
+        ctx.m, ctx.saved, ctx.mid, ctx.top = m, saved, mid, (nc, xc, xpc, invc, w1p, w2p)
+        ctx.out_b, ctx.ctrip, ctx.coef, ctx.rows_p, ctx.slot, ctx.loc = out_b, ctrip, coef, rows_p, slot, loc
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ngcf import _mat_grads
+        m, saved, mid, out_b, ctrip = ctx.m, ctx.saved, ctx.mid, ctx.out_b, ctx.ctrip
+        nc, xc, xpc, invc, w1p, w2p = ctx.top
+        rows_p, slot, loc = ctx.rows_p, ctx.slot, ctx.loc
+        ops, part, dims = m.ops, m.part, m.dims
+        L = len(dims) - 1
+        B = ctrip.shape[0]
+        T, dtot = 3 * B, sum(dims)
+        dev = out_b.device
+        offs = [0]
+        for d in dims:
+            offs.append(offs[-1] + d)
+        d_b = torch.zeros_like(out_b)                      # replicated: every rank holds the whole batch
+        ops.bpr_bwd(out_b[:B], out_b[B:], out_b[:B], out_b[B:], ctrip, ctx.coef, g.contiguous(), d_b[:B], d_b[B:], d_b[:B], d_b[B:])
+        dws = [None] * L
+        # top layer on the T batch rows, identical on every rank: its weight gradients enter the all-reduce from rank 0 only
+        d_nei_c, d_xd_c, dw1, dw2 = ops.ngcf_dense_bwd(None, nc, xc, w1p, w2p, (xpc, invc, d_b[:, offs[L]:], dtot))
+        dws[L - 1] = (dw1, dw2) if m.rank == 0 else (torch.zeros_like(dw1), torch.zeros_like(dw2))
+        dl = dims[L - 1]
+        # the hop onto the local rows: operand = the gathered-layout table, valid on the batch rows only (always flagged)
+        gfull = m._scratch(("ngcf_top", dl), (part.n_pad, dl), torch.float32)
+        gfull.index_fill_(0, rows_p, 0.0)
+        gfull.index_add_(0, rows_p, d_nei_c)
+        fl_full = torch.zeros(part.n_pad, dtype=torch.uint8, device=dev)
+        fl_full.index_fill_(0, rows_p, 1)
+        bfl = torch.zeros(part.per, dtype=torch.uint8, device=dev)       # local batch rows
+        bfl.index_fill_(0, loc, 1)
+        b_loc = torch.empty(part.per, dl, dtype=torch.float32, device=dev)
+        b_loc.index_fill_(0, loc, 0.0)
+        b_loc.index_add_(0, loc, d_xd_c.index_select(0, slot))
+        dx = torch.empty(part.per, dl, dtype=torch.float32, device=dev)  # valid on `mid` (every local row if L == 1)
+        for c in range(part.n_chunks):
+            r = part.chunk_rows(c)
+            ops.last_hop(m.graph_t_chunks[c], gfull, fl_full, None, b_loc[r], 1.0, dx[r], b_flags=bfl[r],
+                         row_mask=mid[r] if mid is not None else None)
+        if L >= 2:
+            ldz = offs[L] - offs[1]
+            dzn = torch.empty(part.per, ldz, dtype=torch.float32, device=dev)          # valid on the local batch rows
+            dzn.index_fill_(0, loc, 0.0)
+            dzn.index_add_(0, loc, d_b[:, offs[1]:offs[L]].index_select(0, slot))
+        for k in range(L - 2, -1, -1):
+            x, nei, xp, inv, w1p, w2p, mk = saved[k]
+            d_nei, d_xd, dw1, dw2 = ops.ngcf_dense_bwd(dx, nei, x, w1p, w2p, (xp, inv, dzn[:, offs[k + 1] - offs[1]:], ldz),
+                                                       row_mask=mk, dz_flags=bfl)
+            dws[k] = (dw1, dw2)
+            saved[k] = None
+            # dX = dX_direct + (A^T dN)[rows_g]; dN of the masked layer travels with its mask as flags (always consulted)
+            if mk is not None:
+                gat = _GradGather(m, d_nei.shape[1], k & 1, True, exact_flags=True)
+                for c in range(part.n_chunks):
+                    r = part.chunk_rows(c)
+                    gat.put(c, d_nei[r], mk[r])
+                gf, ff, _ = gat.result()
+            else:
+                gf, ff = _Gather(m, d_nei.shape[1], key=("ngcf_bwd", k & 1)).put_all(d_nei).table(), None
+            dx = torch.empty_like(x)
+            for c in range(part.n_chunks):
+                r = part.chunk_rows(c)
+                if ff is not None:
+                    ops.last_hop(m.graph_t_chunks[c], gf, ff, None, d_xd[r], 1.0, dx[r], b_flags=mk[r])
+                else:
+                    ops.spmm_axpy(m.graph_t_chunks[c], gf, d_xd[r], 1.0, dx[r])
+        dx.index_add_(0, loc, d_b[:, :dims[0]].index_select(0, slot))
+        gm = _mat_grads(dws)
+        flat = torch.cat([t.reshape(-1) for t in gm])
+        m.all_reduce(flat, "weight_grads")
+        o = 0
+        for i, t in enumerate(gm):
+            gm[i] = flat[o:o + t.numel()].reshape(t.shape)
+            o += t.numel()
+        ctx.saved = ctx.top = None
+        return (None, None, dx, *gm)
+
+
 class _ShardedNgcfLoss(torch.autograd.Function):
     """(table shard, W / b) -> [mul_loss, l2reg_loss(propagated rows)] for a replicated batch; see ShardedNGCF."""
 
@@ -708,8 +861,10 @@ class ShardedNGCF(torch.nn.Module):
     `split_adj_k` folds (adj.py:114-140,158-164) living on different GPUs.  Rank g owns rows_g of the table (parameters,
     Adam state), the row slice A[rows_g, :] and the row slice of A^T (A = D^-1 A + I is not symmetric); W / b are
     replicated and their gradients all-reduced.  Per layer, forward and backward: one pipelined all-gather (of X, of dN),
-    the local product, the local MFMA dense block.  Every layer runs on all rows (the restricted step of the single-GPU
-    model is not ported).  Same `loss(batch)` / `parameters()` surface as `NGCF`; every rank calls with the same batch."""
+    the local product, the local MFMA dense block.  `loss()` runs the compact restricted step (`_ShardedNgcfRestrictedLoss`:
+    2 L - 1 table exchanges instead of 2 L + 1, the top two layers on the rows the batch depends on) when the batch is small
+    against the graph, otherwise every layer on all rows.  Same `loss(batch)` / `parameters()` surface as `NGCF`; every rank
+    calls with the same batch."""
 
     def __init__(self, data, config, rowptr, col, val, n_nodes, ops=None, group=None, n_chunks=None):
         super().__init__()
@@ -737,7 +892,15 @@ class ShardedNGCF(torch.nn.Module):
             return [self.ops.row_block(rp, c, v, k * self.part.rc, (k + 1) * self.part.rc, self.n_pad) for k in range(n_chunks)]
 
         self.graph_chunks = row_blocks(rowptr, col, val)
-        self.graph_t_chunks = row_blocks(*transpose_csr(rowptr, col, val, self.n_nodes))
+        t_global = transpose_csr(rowptr, col, val, self.n_nodes)
+        self.graph_t_chunks = row_blocks(*t_global)
+        # column slice A[:, rows_g] (a CSR over all nodes in gathered order, columns = local rows) = the transpose of the
+        # rank's rows of A^T: marks the local part of the batch rows' neighbourhood and carries the push-form top layer
+        trp, tc, tv = local_csr(*t_global, self.lo, self.hi, self.per)
+        tc = self.part.gathered(tc.to(torch.int64)).to(torch.int32).contiguous()
+        crp, cc, cv = transpose_csr(trp, tc, tv, self.n_pad)
+        self.graph_cols = self.ops.row_block(crp, cc, cv, 0, self.n_pad, self.per)
+        self.restrict_forward = bool(config.get("restrict_forward", True))
         num_list = [self.n_user, self.n_item] + ([data.num["tag"]] if config["use_tag"] else [])
         assert sum(num_list) == self.n_nodes
         full = xavier_tables(num_list, self.dims[0], "cpu")            # same seed on every rank -> same table, same W / b
@@ -768,9 +931,15 @@ class ShardedNGCF(torch.nn.Module):
     def _mats(self):
         return [self.mat[f"{n}_{k}"] for k in range(len(self.dims) - 1) for n in ("W1", "b1", "W2", "b2")]
 
+    restrict_min_ratio = 16          # the restricted step is used when 3 B * this <= number of nodes
+
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
-        res = _ShardedNgcfLoss.apply(self, batch_data, self.table, *self._mats())
+        vec = all(d in (8, 16, 32, 64, 128, 256) for d in self.dims)
+        restricted = (self.restrict_forward and getattr(self.ops, "restrict_forward", False) and vec
+                      and 3 * batch_data.shape[0] * self.restrict_min_ratio <= self.part.n)
+        fn = _ShardedNgcfRestrictedLoss if restricted else _ShardedNgcfLoss
+        res = fn.apply(self, batch_data, self.table, *self._mats())
         return res[0], self.reg * res[1]
 
 

@@ -81,9 +81,10 @@ class CpuOps:
         if out_flags is not None:
             out_flags[k] = (res[k] != 0).any(1).to(torch.uint8)
 
-    def last_hop(self, g, g_in, in_flags, in_count, b, s, out, b_flags=None):
+    def last_hop(self, g, g_in, in_flags, in_count, b, s, out, b_flags=None, row_mask=None):
         bb = b if b_flags is None else torch.where(b_flags.bool()[:, None], b, torch.zeros_like(b))
-        out.copy_(g @ self._flagged(g_in, in_flags, in_count) + s * bb)
+        k = self._keep(row_mask, out.shape[0])
+        out[k] = (g @ self._flagged(g_in, in_flags, in_count) + s * bb)[k]
 
     def rownorm_fwd(self, x):
         den = x.norm(dim=1).clamp_min(1e-12)
@@ -134,23 +135,38 @@ class CpuOps:
         ss[keep] = (full[keep] ** 2).sum(1)
 
     # -- NGCF dense block (same contract as tagrec_amd.ngcf.dense_forward / dense_backward)
-    def ngcf_dense_fwd(self, nei, x, w1p, w2p, xp, inv, z_slot, ldz):
+    def ngcf_dense_fwd(self, nei, x, w1p, w2p, xp, inv, z_slot, ldz, row_mask=None):
         lr = torch.nn.functional.leaky_relu
-        xp.copy_(lr((nei + x) @ w1p, 0.2) + lr((nei * x) @ w2p, 0.2))
-        den = xp.norm(dim=1).clamp_min(1e-12)
-        inv.copy_(1.0 / den)
-        z_slot[:, :xp.shape[1]] = xp / den[:, None]
+        k = self._keep(row_mask, x.shape[0])              # rows outside the mask: neither read nor written
+        v = lr((nei[k] + x[k]) @ w1p, 0.2) + lr((nei[k] * x[k]) @ w2p, 0.2)
+        den = v.norm(dim=1).clamp_min(1e-12)
+        xp[k] = v
+        inv[k] = 1.0 / den
+        if z_slot is not None:
+            z_slot[k, :v.shape[1]] = v / den[:, None]
 
-    def ngcf_dense_bwd(self, dxp, nei, x, w1p, w2p, norm):
+    def ngcf_dense_bwd(self, dxp, nei, x, w1p, w2p, norm, row_mask=None, dz_flags=None):
         xp, inv, dz, _ = norm
-        gx = self._nb(xp, inv, dz[:, :xp.shape[1]])
+        k = self._keep(row_mask, x.shape[0])
+        nan = float("nan")
+        d_nei, d_xd = torch.full_like(x, nan), torch.full_like(x, nan)      # rows outside the mask stay unwritten
+        dzk = dz[k, :xp.shape[1]]
+        if dz_flags is not None:                          # rows flagged zero may hold anything: not read
+            dzk = torch.where(dz_flags.bool()[k][:, None], dzk, torch.zeros_like(dzk))
+            xpk = torch.where(dz_flags.bool()[k][:, None], xp[k], torch.ones_like(xp[k]))
+            invk = torch.where(dz_flags.bool()[k], inv[k], torch.ones_like(inv[k]))
+        else:
+            xpk, invk = xp[k], inv[k]
+        gx = self._nb(xpk, invk, dzk)
         if dxp is not None:
-            gx = gx + dxp
-        a1, a2 = nei + x, nei * x
+            gx = gx + dxp[k]
+        a1, a2 = nei[k] + x[k], nei[k] * x[k]
         slope = lambda p: torch.where(p > 0, torch.ones_like(p), torch.full_like(p, 0.2))
         dp1, dp2 = gx * slope(a1 @ w1p), gx * slope(a2 @ w2p)
         da1, da2 = dp1 @ w1p.t(), dp2 @ w2p.t()
-        return da1 + da2 * x, da1 + da2 * nei, a1.t() @ dp1, a2.t() @ dp2
+        d_nei[k] = da1 + da2 * x[k]
+        d_xd[k] = da1 + da2 * nei[k]
+        return d_nei, d_xd, a1.t() @ dp1, a2.t() @ dp2
 
     # -- column-sharded tables
     def spmm_axpy(self, g, g_in, b, s, out):
@@ -387,7 +403,7 @@ def test_sharded_lightgcn_rejects_asymmetric_normalisation(tmp_path):
     assert "not symmetric" in open(tmp_path / "msg.txt").read()
 
 
-def _ngcf_worker(rank, world, port, out_dir, n_chunks):
+def _ngcf_worker(rank, world, port, out_dir, n_chunks, restricted=False):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -406,6 +422,7 @@ def _ngcf_worker(rank, world, port, out_dir, n_chunks):
         torch.manual_seed(2020)
         m = TD.ShardedNGCF(ds, cfg, torch.from_numpy(csr.rowptr), torch.from_numpy(csr.col), torch.from_numpy(csr.val),
                            csr.shape[0], ops=CpuOps(), n_chunks=n_chunks)
+        m.restrict_min_ratio = 0 if restricted else 10 ** 9      # the toy batch touches most rows: force either path
         full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)])
         with torch.no_grad():
             m.table.zero_()
@@ -433,12 +450,14 @@ def _ngcf_worker(rank, world, port, out_dir, n_chunks):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_chunks", [(2, 1), (3, 2)])
-def test_row_sharded_ngcf_matches_reference_fixture(tmp_path, golden, world, n_chunks):
+@pytest.mark.parametrize("world,n_chunks,restricted", [(2, 1, False), (3, 2, False), (2, 2, True), (3, 1, True)])
+def test_row_sharded_ngcf_matches_reference_fixture(tmp_path, golden, world, n_chunks, restricted):
     """Row-sharded NGCF (non-symmetric D^-1 A + I: the backward multiplies by the rank's rows of A^T; W / b replicated,
-    their gradients all-reduced) against the reference's own run: loss parts, every gradient, parameters after 3 steps."""
+    their gradients all-reduced) against the reference's own run: loss parts, every gradient, parameters after 3 steps.
+    restricted: the compact restricted step (masked layer below the top, push-form top layer on the batch rows, flagged
+    gradient exchange); the double leaves rows outside a mask as NaN, so a read of a row nobody computed fails."""
     port = _free_port()
-    mp.spawn(_ngcf_worker, args=(world, port, str(tmp_path), n_chunks), nprocs=world, join=True)
+    mp.spawn(_ngcf_worker, args=(world, port, str(tmp_path), n_chunks, restricted), nprocs=world, join=True)
     got = np.load(tmp_path / "ngcf.npz")
     fx = golden("ngcf_toy")
     np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)

@@ -204,7 +204,7 @@ def test_bench_starts_its_own_ranks(parallel):
     assert line["config"]["parallelism"].startswith(f"{parallel}-shard")
 
 
-def _ngcf_worker(rank, world, port, out_dir):
+def _ngcf_worker(rank, world, port, out_dir, restricted=False):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -223,6 +223,7 @@ def _ngcf_worker(rank, world, port, out_dir):
         ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
         m = TD.ShardedNGCF(ds, cfg, torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.col).to(dev),
                            torch.from_numpy(csr.val).to(dev), csr.shape[0], n_chunks=2)
+        m.restrict_min_ratio = 0 if restricted else 10 ** 9      # the toy batch touches most rows: force either path
         full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)]).to(dev)
         with torch.no_grad():
             m.table.zero_()
@@ -246,11 +247,13 @@ def _ngcf_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_row_sharded_ngcf_real_kernels(tmp_path, golden):
+@pytest.mark.parametrize("restricted", [False, True])
+def test_two_ranks_row_sharded_ngcf_real_kernels(tmp_path, golden, restricted):
     """Row-sharded NGCF on two ranks with the real kernels (product on the rank's rows of A and of A^T, MFMA dense block,
-    all-reduced W / b gradients) against the parameters the reference reached after three Adam steps."""
+    all-reduced W / b gradients) against the parameters the reference reached after three Adam steps; restricted = the
+    compact restricted step (row-masked product / dense block / weight gradient, push-form top layer, flagged exchange)."""
     port = _free_port()
-    mp.spawn(_ngcf_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_ngcf_worker, args=(2, port, str(tmp_path), restricted), nprocs=2, join=True)
     got = np.load(tmp_path / "ngcf.npz")
     fx = golden("ngcf_toy")
     np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
