@@ -214,6 +214,11 @@ class HipOps:
         return dots
 
 
+# Tests set this to run every collective through torch.distributed even in a group of ONE rank (where the models would
+# otherwise copy): the RCCL calls -- dtypes, contiguity, async handles, stream ordering -- then run on a one-GPU box.
+ALWAYS_COLLECTIVE = False
+
+
 def shard_rows(n, world, n_chunks=1):
     """Rows per rank (a multiple of n_chunks, rounded up) and the padded total."""
     rc = (n + world * n_chunks - 1) // (world * n_chunks)
@@ -294,7 +299,7 @@ class _Gather:
     def put(self, c, block):
         m = self.m
         dst = self.full[m.part.chunk_gathered(c)]
-        if m.world == 1:
+        if m.world == 1 and not ALWAYS_COLLECTIVE:
             dst.copy_(block)
             return
         m.comm_bytes += block.numel() * block.element_size() * (m.world - 1)
@@ -572,14 +577,14 @@ class ShardedLightGCN(torch.nn.Module):
 
     def all_gather(self, x):
         """[per, D] shard -> the gathered [n_pad, D] table in ORIGINAL row order (setup / evaluation helper)."""
-        if self.world == 1:
+        if self.world == 1 and not ALWAYS_COLLECTIVE:
             return x.contiguous()
         full = torch.empty((self.n_pad,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(full, x.contiguous(), group=self.group)
         return full
 
     def all_reduce(self, x, name="all_reduce"):
-        if self.world > 1:
+        if self.world > 1 or ALWAYS_COLLECTIVE:
             e = self._wait_begin()
             self.comm_bytes += x.numel() * x.element_size()
             dist.all_reduce(x, group=self.group)
@@ -1174,7 +1179,7 @@ class FeatureShardedLightGCN(torch.nn.Module):
     timing_ms = ShardedLightGCN.timing_ms
 
     def all_reduce(self, x, name="all_reduce"):
-        if self.world > 1:
+        if self.world > 1 or ALWAYS_COLLECTIVE:
             e = self._wait_begin()
             self.comm_bytes += x.numel() * x.element_size()
             dist.all_reduce(x, group=self.group)

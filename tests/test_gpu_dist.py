@@ -1,7 +1,8 @@
 """GPU: the sharded LightGCN models with the REAL HIP kernels on two ranks.  A one-GPU box cannot host two RCCL ranks
 (one communicator rank per device), so both processes use cuda:0 and exchange through gloo; what is exercised is the
-kernel chain on column slices / row shards together with real inter-process reductions.  RCCL itself is exercised at
-world size 1 in test_gpu_lightgcn.py and by `bench.py --gpus N` on a multi-GPU node."""
+kernel chain on column slices / row shards together with real inter-process reductions.  RCCL itself is exercised in a
+group of ONE rank with every world-1 shortcut switched off (`dist.ALWAYS_COLLECTIVE`: the chunked asynchronous all-gathers,
+the flag gathers and the all-reduces all go through the "nccl" backend) and by `bench.py --gpus N` on a multi-GPU node."""
 import os
 import socket
 
@@ -22,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, kind, fixture="lightgcn_toy"):
+def _worker(rank, world, port, out_dir, kind, fixture="lightgcn_toy", backend="gloo"):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -31,7 +32,11 @@ def _worker(rank, world, port, out_dir, kind, fixture="lightgcn_toy"):
     from oracle import adj as oadj
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if backend == "nccl":                         # RCCL, one rank: run every collective anyway
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+        TD.ALWAYS_COLLECTIVE = True
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         fx = load_golden(fixture)
         csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "bi_norm")
@@ -81,6 +86,23 @@ def test_two_ranks_real_kernels(tmp_path, golden, kind, fixture):
     C5's row width (3 layers), where the restricted row-sharded step uses all of: full layer, masked layer, push-form top."""
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), kind, fixture), nprocs=2, join=True)
+    got = np.load(tmp_path / f"{kind}.npz")
+    fx = golden(fixture)
+    np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
+    np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=2e-5)
+    want = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
+    assert np.abs(got["table"] - want).max() <= 2e-4
+
+
+@pytest.mark.parametrize("kind,fixture", [("row_restricted", "lightgcn_toy_d256"), ("row", "lightgcn_toy"),
+                                          ("feature_restricted", "lightgcn_toy")])
+def test_rccl_group_of_one_runs_every_collective(tmp_path, golden, kind, fixture):
+    """The same three Adam steps over the "nccl" backend (RCCL) in a group of one rank with the world-1 shortcuts off:
+    chunked async all_gather_into_tensor of float and uint8 blocks, all_reduce of the batch-row buffers, on the
+    process group's streams -- API, dtype, contiguity and stream-ordering coverage a one-GPU box can give."""
+    assert dist.is_nccl_available()
+    port = _free_port()
+    mp.spawn(_worker, args=(1, port, str(tmp_path), kind, fixture, "nccl"), nprocs=1, join=True)
     got = np.load(tmp_path / f"{kind}.npz")
     fx = golden(fixture)
     np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
@@ -204,7 +226,7 @@ def test_bench_starts_its_own_ranks(parallel):
     assert line["config"]["parallelism"].startswith(f"{parallel}-shard")
 
 
-def _ngcf_worker(rank, world, port, out_dir, restricted=False):
+def _ngcf_worker(rank, world, port, out_dir, restricted=False, backend="gloo"):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -213,7 +235,11 @@ def _ngcf_worker(rank, world, port, out_dir, restricted=False):
     from oracle import adj as oadj
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+        TD.ALWAYS_COLLECTIVE = True
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         fx = load_golden("ngcf_toy")
         csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "ngcf")
@@ -245,6 +271,18 @@ def _ngcf_worker(rank, world, port, out_dir, restricted=False):
                      **{"p." + k: p.detach().cpu().numpy() for k, p in m.mat.items()})
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_group_of_one_sharded_ngcf(tmp_path, golden):
+    """The restricted row-sharded NGCF step over RCCL (group of one rank, shortcuts off)."""
+    port = _free_port()
+    mp.spawn(_ngcf_worker, args=(1, port, str(tmp_path), True, "nccl"), nprocs=1, join=True)
+    got = np.load(tmp_path / "ngcf.npz")
+    fx = golden("ngcf_toy")
+    np.testing.assert_allclose(got["losses"][0], fx["loss_parts"], rtol=1e-5)
+    np.testing.assert_allclose(got["losses"].sum(1), fx["step3.losses"], rtol=2e-5)
+    want = np.concatenate([fx[f"step3.embed.{t}"] for t in range(3)])
+    assert np.abs(got["table"] - want).max() <= 2e-4
 
 
 @pytest.mark.parametrize("restricted", [False, True])
