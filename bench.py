@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 and the ranks exchange "
                          "through gloo (RCCL wants one device per rank); numbers from such a run are not scaling results")
+    ap.add_argument("--no-fused-adam", action="store_true",
+                    help="keep the optimizer a separate launch (default: LightGCN applies the table's Adam update inside its "
+                         "last backward kernel, same arithmetic)")
     ap.add_argument("--model", choices=["lightgcn", "ngcf", "tgcn", "dgcf", "disengcn"], default="lightgcn",
                     help="lightgcn = C2 (headline); ngcf = C3 (same graph, D^-1 A + I, MFMA dense layers); "
                          "tgcn = C4 (tripartite, 1M/1M/2M nodes, D=128, k=25; use --steps 3 --warmup 1); "
@@ -391,6 +394,8 @@ def main():
             timed_graph = model.graph
         del rp, col, val
     opt = T.Adam(model.parameters(), lr=cfg["lr"])
+    if not sharded and not args.no_fused_adam:
+        opt.fuse_into(model)          # LightGCN: the table's Adam update runs in the epilogue of the last backward product
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
 
@@ -557,7 +562,10 @@ def main():
                           "step": "loss -> backward -> Adam on one batch; same loss and gradients as the all-rows step: rows "
                                   "of the top two forward layers that the batch's loss does not read are not computed, "
                                   "backward products do not fetch operand rows that are exactly zero "
-                                  "(extra.ms_per_step_all_rows_forward = every forward layer on all rows)"},
+                                  "(extra.ms_per_step_all_rows_forward = every forward layer on all rows)"
+                                  + ("; the table's Adam update (torch's arithmetic, bit-identical) runs in the epilogue of the "
+                                     "last backward product instead of a separate launch (--no-fused-adam separates them)"
+                                     if (not sharded and not args.no_fused_adam and args.model in ("lightgcn", "ngcf")) else "")},
                "roofline": roof, "extra": extra}
         if not args.no_cpu and world == 1 and args.model in ("lightgcn", "ngcf") and not sharded:
             out["cpu_baseline"] = cpu_baseline(args, args.model, rp, col, val, n, nu, ni, epoch)

@@ -312,6 +312,14 @@ int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
 int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* v, int64_t n,
                           float lr, float b1, float b2, float eps, int64_t* step_dev, float* coef_dev, void* stream);
 
+/* The last backward hop with the optimizer folded in (training/basic_train.py:19-25: backward() then opt.step()):
+ * row r of A G_in + b_scale B is the gradient of parameter row r; torch.optim.Adam's update (defaults; the arithmetic of
+ * tagrec_adam_f32 at step `step`, counted from 1) is applied to p / m / v [n_rows, D] in the epilogue and no gradient
+ * tensor is written.  in_flags / in_count / b_flags as in tagrec_spmm_axpy_sparse_f32.  G_in must not alias p. */
+int tagrec_spmm_axpy_adam_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags, const unsigned* in_count,
+                              const float* B, float b_scale, const uint8_t* b_flags, float* p, float* m, float* v,
+                              float lr, float b1, float b2, float eps, int64_t step, int D, void* stream);
+
 /* out = srcs[0] + ... + srcs[n_srcs - 1] (1 <= n_srcs <= 8, n floats each, summed left to right) in one pass: the
  * gradient of a table that several consumers read (what autograd's pairwise accumulation does in 3 passes per extra
  * gradient).  `srcs` is a HOST array of device pointers; `out` may alias a source. */

@@ -121,6 +121,8 @@ _SIGNATURES = {
                                 c_void_p, c_void_p],
     "tagrec_transtag_bwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_float, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p],
+    "tagrec_spmm_axpy_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_float, c_float, c_float, c_float, c_int64, c_int, c_void_p],
     "tagrec_sum_n_f32": [c_void_p, c_void_p, c_int, c_int64, c_void_p],
     "tagrec_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int64,
                         c_void_p],

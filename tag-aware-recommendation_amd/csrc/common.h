@@ -59,4 +59,24 @@ __device__ __forceinline__ void drop4(const DropMask& m, int64_t float4_index, f
   d = ((h >> 48) & 0xFFFFu) >= thr ? d * keep : 0.f;
 }
 
+
+// torch.optim.Adam's update of four elements, in torch's operation order (_single_tensor_adam): shared by the Adam
+// kernel (rowops.hip) and the last backward hop's fused epilogue (spmm.hip).
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ adam_f4 adam_update(adam_f4& mi, adam_f4& vi, adam_f4 pi, const adam_f4 gi, float w1, float b2, float w2,
+                                               float step_size, float bc2_sqrt, float eps) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    mi[c] = mi[c] + w1 * (gi[c] - mi[c]);             /* exp_avg.lerp_(grad, 1-b1)            */
+    vi[c] = vi[c] * b2 + (w2 * gi[c]) * gi[c];        /* mul_(b2).addcmul_(grad, grad, 1-b2)  */
+    pi[c] = pi[c] - step_size * (mi[c] / (sqrtf(vi[c]) / bc2_sqrt + eps));
+  }
+  return pi;
+}
+// Optional Adam update in place of a gradient store (EpiArgs::adam): p == nullptr -> off
+struct AdamRow {
+  float* p; float* m; float* v;
+  float w1, b2, w2, step_size, bc2_sqrt, eps;
+};
+
 }  // namespace tagrec

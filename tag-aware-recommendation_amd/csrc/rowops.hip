@@ -434,18 +434,6 @@ __global__ __launch_bounds__(kThreads) void transtag_bwd_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------
 // Adam, 16 B per lane, grid-stride, two iterations (eight 16-byte loads) in flight per lane; every array is streamed
 // once per step and is far larger than the caches, so all accesses are non-temporal.  28 B of traffic per element.
-typedef float adam_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ adam_f4 adam_update(adam_f4& mi, adam_f4& vi, adam_f4 pi, const adam_f4 gi, float w1, float b2, float w2,
-                                               float step_size, float bc2_sqrt, float eps) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    mi[c] = mi[c] + w1 * (gi[c] - mi[c]);             /* exp_avg.lerp_(grad, 1-b1)            */
-    vi[c] = vi[c] * b2 + (w2 * gi[c]) * gi[c];        /* mul_(b2).addcmul_(grad, grad, 1-b2)  */
-    pi[c] = pi[c] - step_size * (mi[c] / (sqrtf(vi[c]) / bc2_sqrt + eps));
-  }
-  return pi;
-}
-
 __global__ __launch_bounds__(kThreads) void adam_kernel(float4* __restrict__ p_, const float4* __restrict__ g_,
                                                         float4* __restrict__ m_, float4* __restrict__ v_, int64_t n4,
                                                         float w1, float b2, float w2, float step_size,

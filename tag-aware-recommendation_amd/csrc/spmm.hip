@@ -17,6 +17,7 @@
 //     written to a partial-sum slab and folded in chunk order by a finishing kernel
 //     (deterministic; no float atomics).
 // HBM-bound: algorithmic bytes per stored entry = 8 + 4*D.
+#include <cmath>
 #include <new>
 
 #include "common.h"
@@ -54,6 +55,10 @@ struct EpiArgs {
   // neither B nor X_raw is read for it (the BPR gradient w.r.t. the layer mean lives on the <= 3 B batch rows).
   // nullptr = read every row.
   const uint8_t* b_flags;
+  // AXPY: when adam.p is set the row's result is the gradient of parameter row r and is consumed on the spot -- the
+  // Adam update of that row (torch's operation order, common.h) replaces the store to Y, which may then be null.  Saves
+  // the gradient's round trip through memory and the optimizer's own launch (the last hop of a LightGCN step).
+  AdamRow adam = AdamRow{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 };
 
 // Streamed-once data (indices, values, epilogue operands, outputs) is moved with non-temporal accesses so it does
@@ -202,13 +207,24 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
       if (lane == 0) e.out_flags[r] = nz != 0.f;
     }
   } else if constexpr (EPI == EPI_AXPY) {
-    if (e.b_flags && !e.b_flags[r]) {
-      if (writer) st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
-    } else {
+    float4 o = acc;
+    if (!(e.b_flags && !e.b_flags[r])) {
       const float4 b = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
-      if (writer)
-        st_stream(reinterpret_cast<float4*>(e.Y) + off, make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y),
-                                                          fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w)));
+      o = make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y), fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w));
+    }
+    if (e.adam.p) {
+      if (writer) {
+        adam_f4 m = __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(e.adam.m) + off);
+        adam_f4 v = __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(e.adam.v) + off);
+        const adam_f4 p = __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(e.adam.p) + off);
+        const adam_f4 q = adam_update(m, v, p, adam_f4{o.x, o.y, o.z, o.w}, e.adam.w1, e.adam.b2, e.adam.w2, e.adam.step_size,
+                                      e.adam.bc2_sqrt, e.adam.eps);
+        __builtin_nontemporal_store(m, reinterpret_cast<adam_f4*>(e.adam.m) + off);
+        __builtin_nontemporal_store(v, reinterpret_cast<adam_f4*>(e.adam.v) + off);
+        __builtin_nontemporal_store(q, reinterpret_cast<adam_f4*>(e.adam.p) + off);
+      }
+    } else if (writer) {
+      st_stream(reinterpret_cast<float4*>(e.Y) + off, o);
     }
   } else if constexpr (EPI == EPI_SS) {
     // column-sharded tables: the row norm needs every shard's columns, so only the local sum of squares is formed
@@ -862,6 +878,27 @@ extern "C" int tagrec_spmm_axpy_sparse_f32(const tagrec_graph* g, const float* G
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_sparse: D must be 8 .. 256, a power of two");
   EpiArgs e{G_out, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, row_mask, b_flags};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_sparse");
+}
+
+// The last hop of a training step with the optimizer folded in: row r of (A G_in + b_scale B) is the gradient of
+// parameter row r, and Adam (torch.optim.Adam defaults, same arithmetic as tagrec_adam_f32 at step `step`) is applied
+// to p / m / v right there; no gradient tensor is written.  The gathered operand must not alias p.
+extern "C" int tagrec_spmm_axpy_adam_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                         const unsigned* in_count, const float* B, float b_scale, const uint8_t* b_flags,
+                                         float* p, float* m, float* v, float lr, float b1, float b2, float eps, int64_t step,
+                                         int D, void* stream) {
+  TAGREC_REQUIRE(B != nullptr && p != nullptr && m != nullptr && v != nullptr, "spmm_axpy_adam: null pointer");
+  TAGREC_REQUIRE(in_flags != nullptr || in_count == nullptr, "spmm_axpy_adam: in_count without in_flags");
+  TAGREC_REQUIRE(step >= 1, "spmm_axpy_adam: step counts from 1");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_adam: D must be 8 .. 256, a power of two");
+  TAGREC_REQUIRE(static_cast<const void*>(G_in) != static_cast<const void*>(p), "spmm_axpy_adam: the gathered operand aliases the parameters");
+  TAGREC_REQUIRE(aligned16(p) && aligned16(m) && aligned16(v), "spmm_axpy_adam: rows must be 16-byte aligned");
+  const double bc1 = 1.0 - pow(static_cast<double>(b1), static_cast<double>(step));      // as tagrec_adam_f32
+  const double bc2 = 1.0 - pow(static_cast<double>(b2), static_cast<double>(step));
+  EpiArgs e{p, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, nullptr, b_flags};
+  e.adam = AdamRow{p, m, v, static_cast<float>(1.0 - static_cast<double>(b1)), b2, static_cast<float>(1.0 - static_cast<double>(b2)),
+                   static_cast<float>(static_cast<double>(lr) / bc1), static_cast<float>(sqrt(bc2)), eps};
+  return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_adam");
 }
 
 extern "C" int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,

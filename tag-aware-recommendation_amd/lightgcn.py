@@ -165,7 +165,7 @@ def restricted_forward(graph, x0, n_layer, rows):
     return out_b, (raws, invs, mid, y_top, inv_top)
 
 
-def restricted_backward(graph_t, rows, d_out_b, state, shape):
+def restricted_backward(graph_t, rows, d_out_b, state, shape, fused=None):
     """Gradient w.r.t. x0 of `restricted_forward` given d_out_b [T, D] = d loss / d out_b.  The chain starts on the batch
     rows (compact), lands on their neighbours (row-masked hop: G is non-zero there only) and spreads from there; every
     operand travels with one flag byte per row and zero rows are not gathered; the normalize-backward / mean terms exist
@@ -199,6 +199,11 @@ def restricted_backward(graph_t, rows, d_out_b, state, shape):
         raws[k] = invs[k] = None          # last use: the 4 N D bytes go back to the allocator before the next hop allocates
         # a masked hop wrote the rows of `mid` only: its flags must always be honoured; a full hop wrote every row
         g, flags, count = gn, fo, (None if masked else cnt)
+    if fused is not None:             # (table, optimizer): the last hop applies Adam to the table, no gradient is written
+        table, opt = fused
+        m, v, step = opt.fused_state(table)
+        graph_t.spmm_axpy_adam(g, flags, count, dz, s, tflag, table.data, m, v, opt.lr, opt.betas, opt.eps, step)
+        return None
     g0 = torch.empty(n, D, dtype=torch.float32, device=dev)
     graph_t.spmm_axpy_sparse(g, flags, count, dz, s, g0, b_flags=tflag)
     return g0
@@ -222,8 +227,10 @@ class _PropagateBprLoss(torch.autograd.Function):
     """table -> [mul_loss, l2reg_loss(ego rows)] in one autograd node."""
 
     @staticmethod
-    def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active, drops=None, seed=0, restrict=True):
+    def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active, drops=None, seed=0, restrict=True,
+                fused_opt=None):
         x0 = table.detach()
+        ctx.fused = (table, fused_opt) if fused_opt is not None else None
         B, D = trip.shape[0], x0.shape[1]
         n = x0.shape[0]
         lib = _lib.load()
@@ -273,11 +280,12 @@ class _PropagateBprLoss(torch.autograd.Function):
                                               _lib.ptr(d_b[0][:B]), _lib.ptr(d_b[0][B:]),
                                               _lib.ptr(d_b[1][:B]) if reg else null, _lib.ptr(d_b[1][B:]) if reg else null,
                                               _lib.stream_ptr()), "bpr_bwd")
-            g0 = restricted_backward(ctx.graph.transpose(), rows, d_b[0], ctx.state, ctx.shape)
+            fused = ctx.fused if (ctx.fused is not None and not ctx.reg_active) else None
+            g0 = restricted_backward(ctx.graph.transpose(), rows, d_b[0], ctx.state, ctx.shape, fused)
             if ctx.reg_active:
                 g0.index_add_(0, rows, d_b[1])                            # L2 term on the ego rows
             ctx.state = ctx.out_b = None
-            return g0, None, None, None, None, None, None, None, None, None, None
+            return g0, None, None, None, None, None, None, None, None, None, None, None
         out, x0, trip = ctx.out, ctx.x0, ctx.trip
         nu, ni, D, B = ctx.n_user, ctx.n_item, x0.shape[1], trip.shape[0]
         d_out = torch.zeros_like(out)
@@ -295,7 +303,7 @@ class _PropagateBprLoss(torch.autograd.Function):
                                               null, null, _lib.ptr(g0[:nu]), _lib.ptr(g0[nu:nu + ni]),
                                               _lib.stream_ptr()), "bpr_bwd(reg)")
         ctx.raws = ctx.invs = ctx.out = None
-        return g0, None, None, None, None, None, None, None, None, None, None
+        return g0, None, None, None, None, None, None, None, None, None, None, None
 
 
 class LightGCN(TableModel):
@@ -323,6 +331,11 @@ class LightGCN(TableModel):
 
     def _fused_ok(self):
         return isinstance(self.norm_adj, Graph)
+
+    def set_fused_optimizer(self, opt):
+        """`Adam.fuse_into(model)`: the compact restricted step (reg == 0) applies the table's Adam update in the epilogue of
+        its last backward product; every other path hands the optimizer a gradient as usual.  None switches it off."""
+        self._fused_opt = opt
 
     def _drops(self):
         """(per-layer drop rates, seed of this forward pass) when message dropout is active, else (None, 0).  The
@@ -363,8 +376,10 @@ class LightGCN(TableModel):
         nu, ni = self.num_list[0], self.num_list[1]
         if self._fused_ok():
             drops, seed = self._drops()
+            fused = getattr(self, "_fused_opt", None) if (self.training and torch.is_grad_enabled()) else None
             res = _PropagateBprLoss.apply(self.table, self._graph(), self.num_layer, nu, ni, batch_data,
-                                          H.loss_kind_id(self.loss_func), self.reg != 0, drops, seed, self.restrict_forward)
+                                          H.loss_kind_id(self.loss_func), self.reg != 0, drops, seed, self.restrict_forward,
+                                          fused)
             return res[0], self.reg * res[1]
         all_users, all_items = self.forward()[:2]
         ego = self.embed

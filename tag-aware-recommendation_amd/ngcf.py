@@ -252,7 +252,7 @@ def restricted_forward(graph, x0, wps, dims, rows):
     return out_b, (saved, mid, (nc, xc, xpc, invc, w1p, w2p))
 
 
-def restricted_backward(graph_t, rows, d_b, state, dims, n):
+def restricted_backward(graph_t, rows, d_b, state, dims, n, fused=None):
     """Gradient of `restricted_forward` given d_b [T, sum(dims)] = d loss / d out_b -> (d_x0 [n, dims[0]], [(dW1', dW2')]).
     The chain starts on the batch rows (compact), lands on their neighbours (row-masked hop) and spreads from there; the
     concat gradient of the lower layers lives on the batch rows (dz_flags), the masked layer's dense backward and weight
@@ -271,8 +271,27 @@ def restricted_backward(graph_t, rows, d_b, state, dims, n):
     d_nei_c, d_xd_c, dw1, dw2 = dense_backward(None, nc, xc, w1p, w2p, norm=(xpc, invc, d_b[:, offs[L]:], dtot))
     dws[L - 1] = (dw1, dw2)
     g, b = _scatter_rows(n, rows, d_nei_c), _scatter_rows(n, rows, d_xd_c)       # valid on the batch rows only
+
+    def last_product(g_in, in_flags, addend, b_flags):
+        """The product that lands on the table: d x0 = A^T g_in + addend (+ the concat gradient's first slot, which lives on
+        the batch rows and is folded into the addend first) -- or, with a fused optimizer, Adam applied in its epilogue."""
+        addend.index_add_(0, rows, d_b[:, :dims[0]])
+        if fused is not None:
+            table, opt = fused
+            m_, v_, step = opt.fused_state(table)
+            graph_t.spmm_axpy_adam(g_in, in_flags, None, addend, 1.0, b_flags, table.data, m_, v_, opt.lr, opt.betas, opt.eps, step)
+            return None
+        out = torch.empty(n, dims[0], dtype=torch.float32, device=dev)
+        if in_flags is None and b_flags is None:
+            graph_t.spmm_axpy(g_in, addend, 1.0, out)
+        else:
+            graph_t.spmm_axpy_sparse(g_in, in_flags, None, addend, 1.0, out, None, b_flags=b_flags)
+        return out
+
+    if L == 1:
+        return last_product(g, tflag, b, tflag), dws
     dx = torch.empty(n, dims[L - 1], dtype=torch.float32, device=dev)
-    graph_t.spmm_axpy_sparse(g, tflag, None, b, 1.0, dx, mid, b_flags=tflag)     # valid on `mid` (every row if L == 1)
+    graph_t.spmm_axpy_sparse(g, tflag, None, b, 1.0, dx, mid, b_flags=tflag)     # valid on `mid`
     if L >= 2:
         dzn = _scatter_rows(n, rows, d_b[:, offs[1]:offs[L]])                    # concat gradient of layers 1 .. L-1
         ldz = dzn.shape[1]
@@ -282,13 +301,14 @@ def restricted_backward(graph_t, rows, d_b, state, dims, n):
                                                row_mask=m, dz_flags=tflag)
         dws[k] = (dw1, dw2)
         saved[k] = None
+        if k == 0:
+            return last_product(d_nei, m, d_xd, m), dws
         dx = torch.empty_like(x)
         if m is not None:
             graph_t.spmm_axpy_sparse(d_nei, m, None, d_xd, 1.0, dx, None, b_flags=m)
         else:
             graph_t.spmm_axpy(d_nei, d_xd, 1.0, dx)
-    dx.index_add_(0, rows, d_b[:, :dims[0]])
-    return dx, dws
+    raise AssertionError("unreachable")
 
 
 def _mat_grads(dws):
@@ -320,8 +340,9 @@ class _PropagateBprLoss(torch.autograd.Function):
     """(table, mats) -> [mul_loss, l2reg_loss(propagated rows)] in one autograd node."""
 
     @staticmethod
-    def forward(ctx, graph, dims, n_user, n_item, trip, loss_kind, drops, seed, table, *mats):
+    def forward(ctx, graph, dims, n_user, n_item, trip, loss_kind, drops, seed, fused_opt, table, *mats):
         x0 = table.detach()
+        ctx.fused = (table, fused_opt) if fused_opt is not None else None
         wps = _wps([m.detach() for m in mats])
         B, n = trip.shape[0], x0.shape[0]
         rows = torch.cat([trip[:, 0], trip[:, 1] + n_user, trip[:, 2] + n_user]) if RESTRICT_FORWARD else None
@@ -362,9 +383,9 @@ class _PropagateBprLoss(torch.autograd.Function):
                                                       _lib.ptr(ctrip), B, _lib.ptr(ctx.coef), _lib.ptr(g.contiguous()), 1.0,
                                                       _lib.ptr(dU), _lib.ptr(dI), _lib.ptr(dU), _lib.ptr(dI), _lib.stream_ptr()),
                        "bpr_bwd")
-            d0, dws = restricted_backward(ctx.graph.transpose(), ctx.rows, d_b, ctx.state, ctx.dims, ctx.n)
+            d0, dws = restricted_backward(ctx.graph.transpose(), ctx.rows, d_b, ctx.state, ctx.dims, ctx.n, ctx.fused)
             ctx.state = ctx.out_b = None
-            return (None, None, None, None, None, None, None, None, d0, *_mat_grads(dws))
+            return (None, None, None, None, None, None, None, None, None, d0, *_mat_grads(dws))
         out, trip, nu, ni = ctx.out, ctx.trip, ctx.nu, ctx.ni
         dtot = out.shape[1]
         d_out = torch.zeros_like(out)
@@ -376,7 +397,7 @@ class _PropagateBprLoss(torch.autograd.Function):
                                                   _lib.ptr(dU), _lib.ptr(dI), _lib.stream_ptr()), "bpr_bwd")
         d0, dws = propagate_backward(ctx.graph.transpose(), d_out, ctx.saved, ctx.dims)
         ctx.saved = ctx.out = None
-        return (None, None, None, None, None, None, None, None, d0, *_mat_grads(dws))
+        return (None, None, None, None, None, None, None, None, None, d0, *_mat_grads(dws))
 
 
 class NGCF(TableModel):
@@ -412,6 +433,11 @@ class NGCF(TableModel):
 
     def _mats(self):
         return [self.mat[f"{n}_{k}"] for k in range(self.num_layer) for n in ("W1", "b1", "W2", "b2")]
+
+    def set_fused_optimizer(self, opt):
+        """`Adam.fuse_into(model)`: the compact restricted step applies the TABLE's Adam update in the epilogue of the product
+        that lands on it (W / b keep ordinary gradients); every other path hands over a table gradient as usual."""
+        self._fused_opt = opt
 
     def _fused_ok(self):
         dl = self.dim_layer_list
@@ -455,8 +481,9 @@ class NGCF(TableModel):
         nu, ni = self.num_list[0], self.num_list[1]
         if self.agg_type == "bi_agg" and self._fused_ok():
             drops, seed = self._drops()
+            fused = getattr(self, "_fused_opt", None) if (self.training and torch.is_grad_enabled()) else None
             res = _PropagateBprLoss.apply(self.norm_adj, tuple(self.dim_layer_list), nu, ni, batch_data,
-                                          H.loss_kind_id(self.loss_func), drops, seed, self.table, *self._mats())
+                                          H.loss_kind_id(self.loss_func), drops, seed, fused, self.table, *self._mats())
             return res[0], self.reg * res[1]
         all_users, all_items = self.forward()[:2]
         loss, reg_loss = H.triplet_loss(all_users, all_items, all_users, all_items, batch_data, self.loss_func)

@@ -32,6 +32,29 @@ class Adam:
         self.state = {}
         self.step_count = 0
         self.capturable = bool(capturable)
+        self._fused_done = set()          # parameters whose update of the current step was applied inside backward()
+
+    def fuse_into(self, model):
+        """Let `model` apply this optimizer's update of its embedding table inside the last kernel of its backward pass
+        (the gradient row is consumed where it is formed: no gradient tensor, no separate Adam launch over the table).
+        The zero_grad() / backward() / step() protocol of basic_train.py:19-25 is unchanged: step() then only counts
+        the step for that parameter.  One backward() per step(); not available with capturable=True.  Models without
+        the hook ignore the call."""
+        if self.capturable:
+            raise _lib.TagrecError("Adam.fuse_into: the fused update keeps its step counter on the host (capturable=False)")
+        if hasattr(model, "set_fused_optimizer"):
+            model.set_fused_optimizer(self)
+        return self
+
+    def fused_state(self, p):
+        """(m, v, step number of the update about to be applied) for a parameter updated inside backward()."""
+        if id(p) in self._fused_done:
+            raise _lib.TagrecError("Adam: a second backward() before step() with a fused update")
+        st = self.state.get(id(p))
+        if st is None:
+            st = self.state[id(p)] = {"m": torch.zeros_like(p.data), "v": torch.zeros_like(p.data), "t": 0}
+        self._fused_done.add(id(p))
+        return st["m"], st["v"], st["t"] + 1
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -46,6 +69,12 @@ class Adam:
         lib = _lib.load()
         self.step_count += 1
         for p in self.params:
+            if id(p) in self._fused_done:             # updated inside backward(): only the step counter moves here
+                self._fused_done.discard(id(p))
+                self.state[id(p)]["t"] += 1
+                if p.grad is None:
+                    continue
+                raise _lib.TagrecError("Adam: parameter with a fused update also received a gradient tensor")
             if p.grad is None:
                 continue
             _lib.require_gpu_tensor(p.data, torch.float32, "Adam parameter")

@@ -324,3 +324,58 @@ def test_graphed_compact_restricted_step_matches_eager(name):
     np.testing.assert_allclose(l1, l0, rtol=5e-5)
     for k in s0:
         assert np.mean(np.abs(s1[k] - s0[k]) <= 2e-4) >= 0.99, k
+
+
+@pytest.mark.parametrize("name", ["lightgcn", "ngcf"])
+def test_adam_fused_into_the_last_backward_hop_is_bit_identical(name):
+    """`Adam.fuse_into(model)`: the compact restricted LightGCN / NGCF step applies the table's Adam update in the epilogue
+    of the backward product that lands on the table (no gradient tensor, no separate launch).  Same arithmetic in the same
+    order: every parameter, exp_avg and exp_avg_sq after four steps are bit-identical to the separate optimizer launch;
+    LightGCN with reg != 0 (an extra term lands on the gradient after the last hop) and the all-rows paths hand over a
+    gradient as usual."""
+    ds = T.synth.make_bipartite_device(6000, 5000, 200_000, seed=11, device=DEV)
+    e = ds.edge_index["train"]
+    norm = "bi_norm" if name == "lightgcn" else "ngcf"
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 6000, 5000, norm)
+    g = T.Graph(rp, col, val, (n, n), symmetric=(name == "lightgcn"))
+    g.transpose()
+    cls = {"lightgcn": T.LightGCN, "ngcf": T.NGCF}[name]
+    for reg, layers in ((0.0, [32, 32, 32]), (1e-3, [32, 32, 32]), (0.0, [32]), (0.0, [32, 16])):
+        cfg = T.get_config(name, use_tag=False, dim_layer_list=layers, dim_latent=32, device=DEV, train_batch=64, reg=reg)
+        out = []
+        for fuse in (False, True):
+            torch.manual_seed(3)
+            m = cls(ds, config=cfg, graph=g)
+            m.train()
+            opt = T.Adam(m.parameters(), lr=0.01)
+            if fuse:
+                opt.fuse_into(m)
+            prod = T.BPR_training_data(ds, config=cfg, seed=9)
+            # batches without a repeated node: index_add on repeated rows is an atomic scatter whose order (hence the last
+            # bit of a sum) changes from run to run, which would hide what is compared here
+            pool = prod.all_train_data[:4096].cpu().numpy()
+            batches, used_u, used_i, cur = [], set(), set(), []
+            for u, i_, j_ in pool:
+                if u in used_u or i_ in used_i or j_ in used_i or i_ == j_:
+                    continue
+                used_u.add(u); used_i.update((i_, j_)); cur.append((u, i_, j_))
+                if len(cur) == 64:
+                    batches.append(torch.tensor(cur, device=DEV)); cur = []; used_u, used_i = set(), set()
+                if len(batches) == 4:
+                    break
+            assert len(batches) == 4
+            losses = []
+            for i in range(4):
+                lossx = m.loss(batches[i])
+                opt.zero_grad()
+                sum(lossx).backward()
+                used_fused = m.table.grad is None
+                opt.step()
+                losses.append([float(v.detach()) for v in lossx])
+            assert all(opt.state[id(p)]["t"] == 4 for p in m.parameters())
+            out.append((losses, [p.detach().clone() for p in m.parameters()],
+                        [opt.state[id(p)][k].clone() for p in m.parameters() for k in ("m", "v")], used_fused))
+        (l0, p0, s0, f0), (l1, p1, s1, f1) = out
+        assert not f0 and f1 == (name == "ngcf" or reg == 0.0)
+        assert l0 == l1
+        assert all(torch.equal(a, b) for a, b in zip(p0, p1)) and all(torch.equal(a, b) for a, b in zip(s0, s1))
