@@ -394,8 +394,8 @@ def main():
             timed_graph = model.graph
         del rp, col, val
     opt = T.Adam(model.parameters(), lr=cfg["lr"])
-    if not sharded and not args.no_fused_adam:
-        opt.fuse_into(model)          # LightGCN: the table's Adam update runs in the epilogue of the last backward product
+    if not args.no_fused_adam:
+        opt.fuse_into(model)          # the table's Adam update runs in the epilogue of the last backward product (models with the hook)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
 
@@ -435,6 +435,12 @@ def main():
     W, K = args.warmup, args.steps
     batches = [epoch[k * B:(k + 1) * B] for k in range(W + K)]
     run_steps(batches[:W])
+    # Python's cyclic collector walks every tracked object of the process when a full collection triggers -- with the
+    # synthetic dataset's structures alive that is a ~30 ms host stall in the middle of a timed step (seen as one 40 ms
+    # window in a rocprofv3 trace of 7.5 ms steps).  Collect now and park what exists in the permanent generation.
+    import gc
+    gc.collect()
+    gc.freeze()
     row_sharded = sharded and parallel == "row"
     probe = collective_probe((model.part.rc, D), dev, world) if (row_sharded and world > 1) else None
     # per-kernel HIP events on the launch stream; a row shard is walked in row blocks, one handle (and event list) each
@@ -565,7 +571,7 @@ def main():
                                   "(extra.ms_per_step_all_rows_forward = every forward layer on all rows)"
                                   + ("; the table's Adam update (torch's arithmetic, bit-identical) runs in the epilogue of the "
                                      "last backward product instead of a separate launch (--no-fused-adam separates them)"
-                                     if (not sharded and not args.no_fused_adam and args.model in ("lightgcn", "ngcf")) else "")},
+                                     if (not args.no_fused_adam and getattr(model, "_fused_opt", None) is not None) else "")},
                "roofline": roof, "extra": extra}
         if not args.no_cpu and world == 1 and args.model in ("lightgcn", "ngcf") and not sharded:
             out["cpu_baseline"] = cpu_baseline(args, args.model, rp, col, val, n, nu, ni, epoch)

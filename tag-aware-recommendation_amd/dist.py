@@ -82,6 +82,11 @@ class HipOps:
         else:
             g.spmm_axpy_sparse(g_in, in_flags, in_count, b, s, out, row_mask=row_mask, b_flags=b_flags)
 
+    def last_hop_adam(self, g, g_in, in_flags, in_count, b, s, b_flags, p, m, v, lr, betas, eps, step):
+        """`last_hop` with Adam folded in: the rows of A g_in + s b are the gradient rows of p and update p / m / v in the
+        epilogue (torch.optim.Adam's arithmetic at step `step`); no gradient is written."""
+        g.spmm_axpy_adam(g_in, in_flags, in_count, b, s, b_flags, p, m, v, lr, betas, eps, step)
+
     def rownorm_fwd(self, x):
         n, D = x.shape
         z = torch.empty_like(x)
@@ -458,6 +463,15 @@ class _ShardedLoss(torch.autograd.Function):
                                   dzf[r] if dzf is not None else None)
                     gat.put(c, gn[r], fo[r] if sparse else None)
                 operand = gat.result()
+            fused = getattr(m, "_fused_opt", None) if (restricted and m.reg == 0 and dzf is not None) else None
+            if fused is not None:          # Adam in the epilogue of the last hop (Adam.fuse_into): no gradient tensor
+                am, av, step = fused.fused_state(m.table)
+                for c in range(part.n_chunks):
+                    r = part.chunk_rows(c)
+                    ops.last_hop_adam(m.graph_chunks[c], operand[0], operand[1], operand[2], d_out[r], s, dzf[r],
+                                      m.table.data[r], am[r], av[r], fused.lr, fused.betas, fused.eps, step)
+                ctx.raws = ctx.invs = ctx.y_top = None
+                return None, None, None
             g0 = torch.empty_like(d_out)
             for c in range(part.n_chunks):
                 r = part.chunk_rows(c)
@@ -605,6 +619,11 @@ class ShardedLightGCN(torch.nn.Module):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
         res = _ShardedLoss.apply(self.table, self, batch_data)
         return res[0], self.reg * res[1]
+
+    def set_fused_optimizer(self, opt):
+        """`Adam.fuse_into(model)`: the restricted step with reg == 0 applies the shard's Adam update in the epilogue of its
+        last hop (per row block); otherwise the optimizer gets a gradient as usual."""
+        self._fused_opt = opt
 
     @torch.no_grad()
     def forward(self):
@@ -1034,6 +1053,15 @@ class _FeatureRestrictedLoss(torch.autograd.Function):
             gn.index_add_(0, rows, nb[k])                  # (batch rows lie inside the mask: the product wrote them)
             fo.index_fill_(0, rows, 1)
             gcur, flags, count = gn, fo, None              # flags always consulted: a masked hop wrote its mask only
+        fused = getattr(m, "_fused_opt", None) if not reg else None
+        if fused is not None:              # Adam in the epilogue of the last hop (Adam.fuse_into): no gradient tensor
+            b = torch.empty(n, Dl, dtype=torch.float32, device=dev)             # the ego layer's share of the mean, batch rows
+            b.index_fill_(0, rows, 0.0)
+            b.index_add_(0, rows, dz)
+            am, av, step = fused.fused_state(m.table)
+            ops.last_hop_adam(m.graph, gcur, flags, count, b, 1.0, tflag, m.table.data, am, av, fused.lr, fused.betas, fused.eps, step)
+            ctx.raws = ctx.at_rows = None
+            return None, None, None
         g0 = torch.empty(n, Dl, dtype=torch.float32, device=dev)
         ops.spmm_flags(m.graph, gcur, flags, count, g0, None, None)
         g0.index_add_(0, rows, dz)                          # the ego layer's share of the mean
@@ -1196,6 +1224,11 @@ class FeatureShardedLightGCN(torch.nn.Module):
         fn = _FeatureRestrictedLoss if restricted else _FeatureShardedLoss
         res = fn.apply(self.table, self, batch_data)
         return res[0], self.reg * res[1]
+
+    def set_fused_optimizer(self, opt):
+        """`Adam.fuse_into(model)`: the restricted step with reg == 0 applies the column slice's Adam update in the epilogue
+        of its last hop; otherwise the optimizer gets a gradient as usual."""
+        self._fused_opt = opt
 
     def gathered_table(self):
         """Full [N, D] table on every rank (checkpointing / evaluation)."""

@@ -86,6 +86,15 @@ class CpuOps:
         k = self._keep(row_mask, out.shape[0])
         out[k] = (g @ self._flagged(g_in, in_flags, in_count) + s * bb)[k]
 
+    def last_hop_adam(self, g, g_in, in_flags, in_count, b, s, b_flags, p, m, v, lr, betas, eps, step):
+        bb = b if b_flags is None else torch.where(b_flags.bool()[:, None], b, torch.zeros_like(b))
+        gr = g @ self._flagged(g_in, in_flags, in_count) + s * bb
+        b1, b2 = betas
+        m.copy_(m + (1.0 - b1) * (gr - m))                 # torch.optim.Adam, in its operation order
+        v.copy_(v * b2 + ((1.0 - b2) * gr) * gr)
+        step_size, bc2_sqrt = lr / (1.0 - b1 ** step), (1.0 - b2 ** step) ** 0.5
+        p.copy_(p - step_size * (m / (v.sqrt() / bc2_sqrt + eps)))
+
     def rownorm_fwd(self, x):
         den = x.norm(dim=1).clamp_min(1e-12)
         return x / den[:, None], 1.0 / den
@@ -504,3 +513,61 @@ def test_shard_helpers():
     assert a.tolist() == [0, 1, 1, 1] and c.tolist() == [5] and v.tolist() == [5.0]
     a, c, v = TD.local_csr(rp, col, val, 0, 3, 3)
     assert a.tolist() == [0, 2, 2, 5] and c.tolist() == [0, 1, 2, 3, 4]
+
+
+def _fused_adam_worker(rank, world, port, out_dir, kind):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tagrec_amd as T
+    from tagrec_amd import dist as TD
+    from oracle import adj as oadj
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        fx = load_golden("lightgcn_toy")
+        csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "bi_norm")
+        cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[64, 64, 64], reg=0.0, device="cpu")
+        ds = T.synth.Dataset()
+        ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
+        full = torch.cat([torch.from_numpy(fx[f"init.embed.{t}"]) for t in range(3)])
+        tables = []
+        for fuse in (False, True):
+            args = (ds, cfg, torch.from_numpy(csr.rowptr), torch.from_numpy(csr.col), torch.from_numpy(csr.val), csr.shape[0])
+            if kind == "feature":
+                m = TD.FeatureShardedLightGCN(*args, ops=CpuOps())
+                with torch.no_grad():
+                    m.table.copy_(full[:, rank * m.dim_local:(rank + 1) * m.dim_local])
+            else:
+                m = TD.ShardedLightGCN(*args, ops=CpuOps(), n_chunks=2)
+                with torch.no_grad():
+                    m.table.zero_()
+                    hi = min(m.hi, full.shape[0])
+                    if hi > m.lo:
+                        m.table[:hi - m.lo] = full[m.lo:hi]
+            m.restrict_min_ratio = 0
+            if fuse:
+                opt = T.Adam(m.parameters(), lr=0.01).fuse_into(m)       # every parameter is fused: no HIP call on the CPU
+            else:
+                opt = torch.optim.Adam(m.parameters(), lr=0.01)
+            for b in fx["batches"][:3]:
+                lossx = m.loss(torch.from_numpy(b))
+                opt.zero_grad()
+                sum(lossx).backward()
+                assert (m.table.grad is None) == fuse
+                opt.step()
+            tables.append(m.gathered_table())
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "fused.npz"), a=tables[0].numpy(), b=tables[1].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world", [("row", 2), ("row", 3), ("feature", 2)])
+def test_sharded_step_with_adam_in_the_last_hop(tmp_path, kind, world):
+    """`Adam.fuse_into(sharded model)`: the restricted step (reg == 0) applies the shard's update inside its last hop (per
+    row block / on the column slice) -- same parameters after three steps as torch.optim.Adam on the gradient."""
+    port = _free_port()
+    mp.spawn(_fused_adam_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
+    got = np.load(tmp_path / "fused.npz")
+    np.testing.assert_allclose(got["b"], got["a"], rtol=0, atol=2e-6)
