@@ -33,7 +33,7 @@ def main():
         ends.append(last)
     which = int(os.environ.get("STEP", "-1"))
     if len(ends) < 2:
-        sys.exit("fewer than two optimizer bursts in the trace")
+        sys.exit("fewer than two optimizer bursts in the trace (LightGCN / NGCF: run bench.py with --no-fused-adam, see step_trace.sh)")
     for i in range(1, len(ends)):
         n_in = sum(1 for s, e, n in rows if s > ends[i - 1] and e <= ends[i])
         print(f"# window {i - len(ends)}: {(ends[i] - ends[i - 1]) / 1e6:.2f} ms, {n_in} launches")

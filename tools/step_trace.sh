@@ -1,5 +1,7 @@
 #!/bin/bash
 # bash tools/step_trace.sh TAG bench.py args...  ->  gpurun_out/step_TAG.csv (per-kernel time of ONE steady-state step)
+# Steps are cut at the optimizer's launches: pass --no-fused-adam for LightGCN / NGCF (their default bench run applies the
+# table's Adam update inside the last backward kernel, which leaves no launch to cut at).
 set -o pipefail
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
