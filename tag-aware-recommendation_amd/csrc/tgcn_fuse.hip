@@ -776,19 +776,23 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
   for (int i = 0; i < AS; ++i) { q_acc[i] = 0.f; p_acc[i] = 0.f; }
   const int64_t it_first = static_cast<int64_t>(blockIdx.x), it_step = static_cast<int64_t>(gridDim.x);
   const int64_t it_end = (n_tiles + 3) / 4;
+  // lane part of the DMA source offsets, once (a VALU instruction costs 1/8 of an MFMA and does not overlap with one)
+  int dma_off[PPW];
+#pragma unroll
+  for (int jj = 0; jj < PPW; ++jj) {
+    const int lrow = (wave * PPW + jj) * RP + dma_row;
+    const int sub = lrow >> 4, i = lrow & 15;
+    dma_off[jj] = ((i >> 2) * DS + (i & 3) + 4 * sub) * DOUT + (dma_unit ^ swz(i)) * 4;
+  }
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int j, int buf) {                     // chunk j of the tile group's stream
     const int h = j / (kBitC * CPH), rem = j % (kBitC * CPH);
     const int c = rem / CPH, b = h * HB + (rem % CPH) * NB;
+    const float* base = Wf + (static_cast<int64_t>(c) * D + 4 * b) * DOUT;
 #pragma unroll
-    for (int jj = 0; jj < PPW; ++jj) {
-      const int p = wave * PPW + jj;
-      const int lrow = p * RP + dma_row;
-      const int sub = lrow >> 4, i = lrow & 15;
-      const int u = dma_unit ^ swz(i);
-      const float* src = Wf + (static_cast<int64_t>(c) * D + (i >> 2) * DS + (i & 3) + 4 * (b + sub)) * DOUT + u * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)&wbuf[buf][p * 1024], 16, 0, 0);
-    }
+    for (int jj = 0; jj < PPW; ++jj)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_off[jj]),
+                                       (__attribute__((address_space(3))) void*)&wbuf[buf][(wave_s * PPW + jj) * 1024], 16, 0, 0);
   };
   int cur = 0;
   if (it_first < it_end) { issue(0, 0); issue(1, 1); }
