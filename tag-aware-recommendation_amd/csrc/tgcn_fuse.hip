@@ -293,19 +293,25 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_fwd_lds_kernel(
   const int row_in_piece = lane / lanes_per_row, c4 = lane % lanes_per_row;
   // this lane's read base inside a buffer (see the layout above)
   const int read_base = q * (kEC / RP) * 1024 + q * 32 + (q & 1) * SHIFT + r * OB * 4;
+  // lane part of the DMA source offsets, once (a VALU instruction costs 1/8 of an MFMA and does not overlap with one)
+  int dma_off[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int lrow = (wave * PPW + j) * RP + row_in_piece;            // LDS row -> (q', el)
+    dma_off[j] = ((lrow / kEC) * DS + lrow % kEC) * DOUT + c4 * 4;
+  }
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     U = fresh(U); qv = fresh(qv); pv = fresh(pv); wb = fresh(wb); w1 = fresh(w1); w2 = fresh(w2); w3 = fresh(w3);
     Wf = fresh(Wf); bf = fresh(bf);
     auto issue = [&](int c, int ec, int buf) {
+      const float* base = Wf + (static_cast<int64_t>(c) * D + ec * kEC) * DOUT;
 #pragma unroll
       for (int j = 0; j < PPW; ++j) {
-        const int p = wave * PPW + j;
-        const int lrow = p * RP + row_in_piece;            // LDS row -> (q', el)
-        const int qq = lrow / kEC, el = lrow % kEC;
-        const float* src = Wf + (static_cast<int64_t>(c) * D + qq * DS + ec * kEC + el) * DOUT + c4 * 4;
+        const int p = wave_s * PPW + j;
         const int pq = (p * RP) / kEC;
         char* dst = &wbuf[buf][p * 1024 + pq * 32 + (pq & 1) * SHIFT];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_off[j]),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     };
