@@ -66,7 +66,7 @@ def propagate_forward(graph, x0, n_layer, drops=None, seed=0, loss_rows=None, ma
     return out, raws, invs
 
 
-def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0, masks=None):
+def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0, masks=None, fused=None):
     """Gradient of `propagate_forward` w.r.t. x0 given d_out (dense [N,D]).
     G^L = nb(X^L);  G^k = A^T G^(k+1) + nb(X^k);  G^0 = A^T G^1 + s*d_out,  nb = normalise-backward of s*d_out.
     With dropout each G^k (k >= 1) is multiplied by layer k's mask / (1 - p) before it travels on (it is the gradient
@@ -109,6 +109,11 @@ def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0, masks=Non
         else:
             graph_t.spmm_normbwd(g, raws[k], invs[k], d_out, s, gn, drops[k] if drops else 0.0, _layer_seed(seed, k))
         g = gn
+    if fused is not None and sparse:      # (table, optimizer): Adam in the epilogue of the last hop, no gradient tensor
+        table, opt = fused
+        m, v, step = opt.fused_state(table)
+        graph_t.spmm_axpy_adam(g, flags[cur], counts[cur:cur + 1], d_out, s, None, table.data, m, v, opt.lr, opt.betas, opt.eps, step)
+        return None
     g0 = torch.empty_like(d_out)
     if sparse:
         graph_t.spmm_axpy_sparse(g, flags[cur], counts[cur:cur + 1], d_out, s, g0)
@@ -294,7 +299,8 @@ class _PropagateBprLoss(torch.autograd.Function):
                                           _lib.ptr(ctx.coef), _lib.ptr(g), 1.0,
                                           _lib.ptr(d_out[:nu]), _lib.ptr(d_out[nu:nu + ni]), null, null,
                                           _lib.stream_ptr()), "bpr_bwd")
-        g0 = propagate_backward(ctx.graph.transpose(), d_out, ctx.raws, ctx.invs, ctx.drops, ctx.seed, ctx.masks)
+        fused = ctx.fused if (ctx.fused is not None and not ctx.reg_active and len(ctx.raws) >= 1) else None
+        g0 = propagate_backward(ctx.graph.transpose(), d_out, ctx.raws, ctx.invs, ctx.drops, ctx.seed, ctx.masks, fused)
         # L2 term on the ego rows: added after the propagation hop has written g0
         if ctx.reg_active:
             Ue, Ie = x0[:nu], x0[nu:nu + ni]

@@ -340,8 +340,12 @@ def test_adam_fused_into_the_last_backward_hop_is_bit_identical(name):
     g = T.Graph(rp, col, val, (n, n), symmetric=(name == "lightgcn"))
     g.transpose()
     cls = {"lightgcn": T.LightGCN, "ngcf": T.NGCF}[name]
-    for reg, layers in ((0.0, [32, 32, 32]), (1e-3, [32, 32, 32]), (0.0, [32]), (0.0, [32, 16])):
-        cfg = T.get_config(name, use_tag=False, dim_layer_list=layers, dim_latent=32, device=DEV, train_batch=64, reg=reg)
+    for reg, layers, restrict in ((0.0, [32, 32, 32], True), (1e-3, [32, 32, 32], True), (0.0, [32], True), (0.0, [32, 16], True),
+                                 (0.0, [32, 32], False)):           # restrict False: LightGCN's all-rows path fuses too
+        if name == "ngcf" and not restrict:
+            continue
+        cfg = T.get_config(name, use_tag=False, dim_layer_list=layers, dim_latent=32, device=DEV, train_batch=64, reg=reg,
+                           restrict_forward=restrict)
         out = []
         for fuse in (False, True):
             torch.manual_seed(3)
