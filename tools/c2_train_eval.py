@@ -24,7 +24,7 @@ rp, col, val, n = T.graph.bipartite_norm_device(train[:, 0], train[:, 1], nu, ni
 G = T.Graph(rp, col, val, (n, n), symmetric=True)
 torch.manual_seed(2020)
 model = T.LightGCN(ds, config=cfg, graph=G)
-opt = T.Adam(model.parameters(), lr=0.01)
+opt = T.Adam(model.parameters(), lr=0.01).fuse_into(model)      # the table update runs inside the last backward kernel
 prod = T.BPR_training_data(ds, config=cfg, seed=2020)
 tester = T.Basic_test(ds, config=cfg, with_auc=False)
 users = torch.unique(test[:, 0])[:100_000]
