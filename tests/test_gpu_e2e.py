@@ -191,6 +191,45 @@ def test_c5_width_restricted_step_equals_all_rows_step_at_full_c2_size(c2_graph)
     assert float(((g1 - g0).abs() - 1e-3 * g0.abs()).max()) <= 1e-5 * scale
 
 
+def test_c2_step_with_adam_in_the_last_hop_is_bit_identical(c2_graph):
+    """BASELINE's configuration itself (C2: LightGCN L = 3, D = 64, 2 M nodes, nnz 100 M, B = 512): two training steps with
+    the table's Adam update applied in the epilogue of the last backward product (`Adam.fuse_into`, what bench.py times)
+    against the separate optimizer launch: table, exp_avg and exp_avg_sq bit-identical (batches without a repeated node,
+    so that no atomic scatter reorders a sum between the two runs)."""
+    g, e = c2_graph
+    nu = ni = 1_000_000
+    ds = T.synth.Dataset()
+    ds.num = {"user": nu, "item": ni}
+    cfg = T.get_config("lightgcn", use_tag=False, dim_latent=64, dim_layer_list=[64] * 3, device=DEV, train_batch=512)
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    users = torch.randperm(nu, device=DEV, generator=gen)[:1024]
+    items = torch.randperm(ni, device=DEV, generator=gen)[:2048]
+    batches = [torch.stack([users[i * 512:(i + 1) * 512], items[i * 1024:i * 1024 + 512], items[i * 1024 + 512:(i + 1) * 1024]], 1)
+               for i in range(2)]
+    out = []
+    for fuse in (False, True):
+        torch.manual_seed(5)
+        m = T.LightGCN(ds, config=cfg, graph=g)
+        m.train()
+        opt = T.Adam(m.parameters(), lr=0.01)
+        if fuse:
+            opt.fuse_into(m)
+        losses = []
+        for b in batches:
+            lossx = m.loss(b)
+            opt.zero_grad()
+            sum(lossx).backward()
+            assert (m.table.grad is None) == fuse
+            opt.step()
+            losses.append([float(v.detach()) for v in lossx])
+        st = opt.state[id(m.table)]
+        out.append((losses, m.table.detach().clone(), st["m"].clone(), st["v"].clone()))
+        del m, opt
+    (l0, t0, m0, v0), (l1, t1, m1, v1) = out
+    assert l0 == l1
+    assert torch.equal(t0, t1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+
+
 @pytest.fixture(scope="module")
 def c3_graph(c2_graph):
     """C3 = the C2 graph under NGCF's normalisation D^-1 A + I (adj.py:82-83): not symmetric, so the backward multiplies by
