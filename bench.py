@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-fp32 MFMA = the fp32 vector rate
 
 
 def parse():
@@ -52,16 +53,24 @@ def parse():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--big-batch", type=int, default=786432, help="also report triplets/s at this batch (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-steps", type=int, default=1,
-                    help="timed steps of the CPU baseline on the full workload graph (a C2 step takes the 16 host threads "
-                         "about 70 s; with more than one step a warm-up step runs first)")
+    ap.add_argument("--cpu-steps", type=int, default=3,
+                    help="timed steps of the CPU baseline on the full workload graph after one warm-up step (SURVEY.md 8d: "
+                         ">= 3 timed steps at C2/C3; a C2 step takes the 16 host threads about 70 s)")
+    ap.add_argument("--cpu-budget-s", type=float, default=330.0,
+                    help="wall-clock cap of the CPU baseline leg: if the warm-up step shows that --cpu-steps timed steps "
+                         "would not fit, fewer are timed (never fewer than one) and the line says so")
+    ap.add_argument("--no-probes", action="store_true", help="skip the measured-ceiling probes (stream triad, row gathers)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short C3 (NGCF) and C4 (TGCN) legs that the default C2 run appends under extra.configs")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded model even with one rank (exercises dist.py + RCCL init on one GPU)")
-    ap.add_argument("--parallel", choices=["auto", "feature", "row"], default="auto",
+    ap.add_argument("--parallel", choices=["auto", "feature", "row", "both"], default="auto",
                     help="multi-GPU sharding of the node table: row = row ranges (the reference's folds; default from 8 "
-                         "ranks), feature = columns (default up to 4 ranks when dim / ranks >= 16)")
+                         "ranks), feature = columns (default up to 4 ranks when dim / ranks >= 16); both = time the two "
+                         "partitions one after the other in the same job: the line is the one `auto` picks, the other is "
+                         "printed under extra.partitions")
     ap.add_argument("--chunks", type=int, default=0, help="row blocks per shard for the pipelined all-gathers (0 = default)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 and the ranks exchange "
@@ -117,7 +126,8 @@ def committed_traffic(model, D, kname):
                                            "not re-measured by this run")
 
 
-def _cpu_steps(om, model_kind, tabs, mats, A, layers, batches, n_warm):
+def _cpu_steps(om, model_kind, tabs, mats, A, layers, batches, budget_s):
+    """One warm-up step, then up to len(batches) - 1 timed steps; fewer if the warm-up shows they would not fit `budget_s`."""
     params = tabs + mats
     opt = torch.optim.Adam(params, lr=0.01)
     if model_kind == "ngcf":
@@ -125,10 +135,13 @@ def _cpu_steps(om, model_kind, tabs, mats, A, layers, batches, n_warm):
         fn = lambda b: om.ngcf_loss(tabs, W, A, layers, b, 0.0, "logsigmoid")
     else:
         fn = lambda b: om.lightgcn_loss(tabs, A, layers, b, 0.0, "softplus")
-    om.adam_epoch(params, fn, batches[:n_warm], opt)
     t0 = time.perf_counter()
-    om.adam_epoch(params, fn, batches[n_warm:], opt)
-    return (time.perf_counter() - t0) / (len(batches) - n_warm)
+    om.adam_epoch(params, fn, batches[:1], opt)
+    t_warm = time.perf_counter() - t0
+    n_timed = max(1, min(len(batches) - 1, int((budget_s - t_warm) / max(t_warm, 1e-3))))
+    t0 = time.perf_counter()
+    om.adam_epoch(params, fn, batches[1:1 + n_timed], opt)
+    return (time.perf_counter() - t0) / n_timed, n_timed, t_warm
 
 
 def _ngcf_keys(layers):
@@ -139,15 +152,13 @@ def cpu_baseline(args, model_kind, rp, col, val, n, nu, ni, epoch):
     """The CPU oracle (oracle/models.py: torch.sparse.mm on a COO tensor built like the reference's sp2tensor, F.normalize,
     softplus / logsigmoid, autograd, torch.optim.Adam -- checked op for op against the imported reference, tests/golden)
     timed on THIS workload: the same graph the GPU leg just ran (its CSR copied to the host), the same batch size,
-    1 warm-up + `--cpu-steps` timed steps on the host cores of the box.  `extra_sample` repeats the round-1 figure
-    (a 1/8-scale graph scaled by stored entries) for comparison."""
+    1 warm-up + `--cpu-steps` timed steps on the host cores of the box."""
     from oracle import adj as oadj, models as om
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))   # the box gives a one-GPU job a 16-core share of the host
     torch.set_num_threads(cores)
     D, L, B = args.dim, args.layers, args.batch
-    n_timed = max(1, args.cpu_steps)
-    n_warm = 1 if n_timed > 1 else 0        # a step is ~10^2 s of sparse products: first-call effects are far below 1 %
-    print(f"[bench] cpu_baseline: {model_kind} oracle on the full graph (nnz={int(rp[-1])}), {n_warm}+{n_timed} steps, "
+    want = max(1, args.cpu_steps)
+    print(f"[bench] cpu_baseline: {model_kind} oracle on the full graph (nnz={int(rp[-1])}), 1+{want} steps, "
           f"{cores} threads ...", file=sys.stderr, flush=True)
     A = om.csr_to_torch(oadj.CSR(rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(), (n, n)))
     tabs = [t.requires_grad_() for t in om.xavier_tables([(nu, D), (ni, D)], 2020)]
@@ -158,19 +169,63 @@ def cpu_baseline(args, model_kind, rp, col, val, n, nu, ni, epoch):
                 t = torch.empty(*shp)
                 torch.nn.init.xavier_uniform_(t)
                 mats.append(t.requires_grad_())
-    batches = [epoch[k * B:(k + 1) * B].cpu() for k in range(n_warm + n_timed)]
-    dt = _cpu_steps(om, model_kind, tabs, mats, A, L, batches, n_warm)
+    batches = [epoch[k * B:(k + 1) * B].cpu() for k in range(1 + want)]
+    dt, n_timed, t_warm = _cpu_steps(om, model_kind, tabs, mats, A, L, batches, args.cpu_budget_s)
     name = "NGCF" if model_kind == "ngcf" else "LightGCN"
     return {"value": B / dt, "unit": "triplets/s", "cores": cores, "kind": "port", "ms_per_step": dt * 1e3,
+            "steps_timed": n_timed, "warmup_steps": 1,
             "sample": f"CPU oracle (torch {torch.__version__} CPU ops, {cores} threads), {name} L={L} D={D} B={B} on the FULL "
-                      f"workload graph ({nu} x {ni}, nnz={int(rp[-1])}): {dt:.2f} s/step measured over {n_timed} steps after "
-                      f"{n_warm} warm-up step(s); no scaling applied (the 1+3-step run of the same leg is kept in "
-                      f"profiles/r02_bench_c2_cpu3.log)"}
+                      f"workload graph ({nu} x {ni}, nnz={int(rp[-1])}): {dt:.2f} s/step over {n_timed} timed steps after 1 "
+                      f"warm-up step ({t_warm:.1f} s)"
+                      + ("" if n_timed == want else f"; {want} were asked for, the {args.cpu_budget_s:.0f} s budget of this leg fitted {n_timed}")
+                      + "; no scaling applied"}
 
 
-def bench_tgcn(args):
+def probe_ceilings(dev, reps=5):
+    """Measured ceilings of THIS box, taken before the timed region with two minimal kernels of the library
+    (csrc/probe.hip): a stream triad over 3 x 1 GiB (HBM streaming) and random whole-row gathers of 256-byte rows -- the
+    access shape of the D = 64 neighbour gather -- from tables of 256 MB (fits the Infinity Cache), 512 MB (the C2 table)
+    and 4 GB (HBM).  GB/s of the bytes each kernel is asked to move (12 B per triad element; row + 4-byte index per gather)."""
+    from tagrec_amd import _lib
+    lib = _lib.load()
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for i in range(reps):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        return min(ev[i].elapsed_time(ev[i + 1]) for i in range(reps)) * 1e-3
+
+    out = {}
+    n = 1 << 28
+    a, b, c = (torch.empty(n, device=dev) for _ in range(3))
+    b.fill_(1.0); c.fill_(2.0)
+    t = timed(lambda: _lib.check(lib.tagrec_probe_triad_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), 0.5, n, _lib.stream_ptr()), "triad"))
+    out["stream_triad_3x1GiB"] = 12.0 * n / t / 1e9
+    del a, b, c
+    n_idx = 1 << 26
+    sink = torch.empty(lib.tagrec_probe_gather_out_floats(), device=dev)
+    table = torch.empty((4 << 30) // 256, 64, device=dev).normal_()
+    for label, mb in (("gather_256B_rows_from_256MB", 256), ("gather_256B_rows_from_512MB", 512), ("gather_256B_rows_from_4GB", 4096)):
+        rows = (mb << 20) // 256
+        idx = torch.randint(0, rows, (n_idx,), device=dev, dtype=torch.int32)
+        t = timed(lambda: _lib.check(lib.tagrec_probe_gather_rows_f32(_lib.ptr(table), rows, 64, _lib.ptr(idx), n_idx, _lib.ptr(sink),
+                                                                      _lib.stream_ptr()), "gather"))
+        out[label] = n_idx * 260.0 / t / 1e9
+        del idx
+    del table, sink
+    torch.cuda.empty_cache()
+    return {k: round(v, 1) for k, v in out.items()}
+
+
+def bench_tgcn(args, ceilings=None):
     """C4: TGCN 3-layer dim 128 on a synthetic tripartite graph (1M users, 1M items, 2M tags, 100M
-    assignments, k=25 neighbours per relation).  A step = one BPR mini-batch of `epoch_training` phase 0."""
+    assignments, k=25 neighbours per relation).  A step = one BPR mini-batch of `epoch_training` phase 0.
+    Returns the JSON object of the line."""
     import tagrec_amd as T
     from tagrec_amd import tgcn as TG
     dev = torch.device("cuda", 0)
@@ -246,24 +301,35 @@ def bench_tgcn(args):
                 "all_rows_kernels_ms": {kk: sum(v) / len(v) for kk, v in full_ms.items() if kk != "attn_fwd"},
                 "step_kernels_ms_per_step": {kk: sum(v) / K for kk, v in ms.items()}}
     n_nodes = nu + ni + nt
+    # the other bounding roofline of C4: the fusion product of the fused dense kernel on the MFMA pipe
+    fuse_all = full_ms.get("fuse_fwd", [])
+    roof_mfma = None
+    if fuse_all:
+        tf = L * 2 * n_nodes * (32 * D + 48) * D / 1e12 / (sum(fuse_all) * 1e-3)
+        roof_mfma = {"bound": "mfma", "kernel": "tgcn_fuse_fwd kernel (type attention + convolutions + fusion layer), all rows, "
+                                                "flops of the fusion product 2 n (32 D + 48) D only",
+                     "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "ms_all_rows_per_layer": sum(fuse_all) / L}
+    if roof is not None and ceilings:
+        roof["measured_ceilings"] = ceilings
     out = {"metric": f"BPR triplets/sec, TGCN {L}-layer dim{D}, tripartite {nu}/{ni}/{nt} nodes, k={k}",
            "value": K * B / dt, "unit": "triplets/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"C4 TGCN L={L} D={D} users={nu} items={ni} tags={nt} assignments={int(ds.uit_data.shape[0])} "
                                   f"k={k} train_batch={B} adam lr=0.01 logsigmoid", "train_batch": B, "parallelism": "single"},
-           "roofline": roof, "cpu_baseline": "not run (the reference cannot materialise this size: 4 M x (32 D + 48) floats "
-                                             "of convolution output per layer)",
-           "extra": {"build_s": round(t_build, 1), "last_loss": [float(x) for x in last],
+           "roofline": roof, "roofline_mfma": roof_mfma,
+           "cpu_baseline": "not run (the reference cannot materialise this size: 4 M x (32 D + 48) floats "
+                           "of convolution output per layer)",
+           "extra": {"build_s": round(t_build, 1), "last_loss": [float(x.detach()) for x in last],
                      "transtag_step_ms": t_tt * 1e3,
                      "attention_ms_per_step": (sum(ms.get("attn_fwd", [])) + sum(ms.get("attn_bwd", []))) / K,
                      "pruned_forward": bool(model.prune_forward),
                      "fused_dense_ms_per_step": sum(sum(ms.get(kk, [])) for kk in ("fuse_fwd", "fuse_bwd", "fuse_wf")) / K,
-                     "fused_fwd_all_rows_tflops": L * 2 * n_nodes * (32 * D + 48) * D / 1e12 / max(1e-9, sum(full_ms.get("fuse_fwd", [])) * 1e-3),
                      "note": "type attention + convolutions + fusion layer = fused MFMA kernels (csrc/tgcn_fuse.hip: fwd, bwd-data, "
-                             "bwd-Wf); neighbour attention = csrc/tgcn.hip with pull-form backward through the SpMM kernel; "
-                             "the projections P/Q/WT and the small weight gradients are plain rocBLAS GEMMs; "
-                             "the CPU reference cannot materialise this size"}}
-    print(json.dumps(out))
+                             "bwd-Wf); neighbour attention = csrc/tgcn.hip; the CPU reference cannot materialise this size"}}
+    del model, opt, prod, ds
+    torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(args):
@@ -313,38 +379,13 @@ def collective_probe(shape, dev, world, reps=5):
     return out
 
 
-def main():
-    args = parse()
-    if args.model == "tgcn":
-        return bench_tgcn(args)
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args))
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    args.gpus = world
-    if args.share_gpu:
-        local = 0
-    assert torch.cuda.is_available(), "bench.py needs a GPU (tagrec_amd has no CPU path)"
-    if local >= torch.cuda.device_count():
-        sys.exit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} GPU(s) are visible "
-                 "(one rank per GPU; --share-gpu for a rehearsal)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+def run_table_model(args, dev, rank, world, sharded, ceilings=None, ds=None, light=False):
+    """One table-model leg (LightGCN = C2 headline, NGCF = C3, DGCF / DisenGCN on the C2 graph; single GPU or sharded):
+    build, warm up, time exactly `args.steps` steps between barriers.  Returns (JSON object of the line, inputs of the CPU
+    baseline leg, the dataset for a following leg on the same graph).  light: no all-rows / big-batch variants."""
     import tagrec_amd as T
-
-    sharded = world > 1 or args.force_shard
     if sharded:
         import torch.distributed as dist
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        if args.share_gpu and world > 1:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
         from tagrec_amd import dist as TD
 
     nu = ni = max(int(1_000_000 * args.scale), 2000)
@@ -364,6 +405,20 @@ def main():
         # GPU (5.5x at 8 ranks), where the row partition would move 4 x 2.56 GB per link and step (~160 ms).
         col_ok = D % world == 0 and D // world >= 8
         parallel = "feature" if (col_ok and (D // world >= 32 or world <= 4)) else "row"
+    parallelism_note = None
+    if sharded and args.parallel == "auto" and parallel != "row" and args.model == "lightgcn":
+        # BASELINE.json's multi-GPU configuration names the ROW partition ("embedding tables row-sharded ... RCCL
+        # all-reduce"); `auto` deviates from it here, so say so and put both projections side by side
+        tab_mb = 2 * nu * D * 4 / 1e6
+        link_ms = 4 * (tab_mb / world) / 64.0             # four shard exchanges per step, one shard per xGMI link, 64 GB/s
+        parallelism_note = (
+            f"DEVIATION from the north star's row partition: --parallel auto picked the COLUMN (feature) partition at "
+            f"{world} ranks (D / ranks = {D // world}).  Row partition (the reference's split_adj_k folds): 4 table-shard "
+            f"exchanges per step = {4 * tab_mb / world:.0f} MB per xGMI link = ~{link_ms:.1f} ms at 64 GB/s per direction "
+            f"before compute (projection, DESIGN.md section 6: C2 ~20 / 10.4 / 5.4 ms per step at 2 / 4 / 8 ranks, C5 ~160 ms at 8); "
+            f"column partition: three all-reduces of a few KB per step, per-rank slice measured on one GPU "
+            f"(C2: 7.4 / 7.0 / 6.7 ms at 2 / 4 / 8 ranks, C5 at 8 ranks: 79 ms vs 436 ms on one GPU).  Run --parallel row, "
+            f"or --parallel both for the two partitions in one job.")
     Dl = D // world if (sharded and parallel == "feature") else D
     if args.model not in ("lightgcn", "ngcf") and sharded:
         sys.exit(f"bench.py: the sharded path covers LightGCN (C2/C5) and NGCF (C3); run --model {args.model} on one GPU")
@@ -372,7 +427,8 @@ def main():
     routed = args.model in ("dgcf", "disengcn")
 
     t0 = time.perf_counter()
-    ds = T.synth.make_bipartite_device(nu, ni, ne, seed=1, device=dev)
+    if ds is None:
+        ds = T.synth.make_bipartite_device(nu, ni, ne, seed=1, device=dev)
     if args.model == "disengcn":
         ds.num["tag"] = 0                   # the reference's DisenGCN always carries a tag table; empty here
     e = ds.edge_index["train"]
@@ -476,7 +532,7 @@ def main():
              "edge_layers_per_s": nnz * L * 2 * K / dt}
     if comm is not None:
         extra["collectives"] = comm
-    if args.model == "lightgcn" and not sharded and getattr(model, "restrict_forward", False):
+    if args.model == "lightgcn" and not sharded and not light and getattr(model, "restrict_forward", False):
         # the same step with every forward layer computed on ALL rows (the timed step above computes the top two
         # layers only on the rows the batch's loss depends on -- same loss and gradients)
         model.restrict_forward = False
@@ -485,7 +541,7 @@ def main():
         model.restrict_forward = True
         extra["ms_per_step_all_rows_forward"] = dtf / K * 1e3
         extra["triplets_per_s_all_rows_forward"] = K * B / dtf
-    if args.big_batch and epoch.shape[0] >= args.big_batch * 3 and not sharded:
+    if args.big_batch and epoch.shape[0] >= args.big_batch * 3 and not sharded and not light:
         BB = args.big_batch
         bb = [epoch[k * BB:(k + 1) * BB] for k in range(3)]
         run_steps(bb[:1])
@@ -540,10 +596,23 @@ def main():
             # rate of the bytes that did cross the L2 <-> fabric boundary (HBM + Infinity Cache), from the PMC passes
             roof["frac_counter"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof["refetch_factor"] = traffic / comp
+        if ceilings:
+            # ceilings MEASURED on this box before the timed region (probe_ceilings): what a stripped gather of the same
+            # row shape reaches from a table of the workload's size, and the HBM streaming rate
+            roof["measured_ceilings"] = ceilings
+            tab_mb = timed_graph.shape[1] * Dl * 4 / 2 ** 20
+            gkey = ("gather_256B_rows_from_256MB" if tab_mb <= 256 else
+                    "gather_256B_rows_from_512MB" if tab_mb <= 1024 else "gather_256B_rows_from_4GB")
+            if Dl == 64 and ceilings.get(gkey):
+                roof["gather_ceiling"] = gkey
+                roof["frac_of_gather_ceiling"] = ach / ceilings[gkey]
+            if ceilings.get("stream_triad_3x1GiB"):
+                roof["frac_of_stream_triad"] = ach / ceilings["stream_triad_3x1GiB"]
         if roof["frac"] > 1.0:
             roof["note"] = ("frac > 1: `achieved` bills every gathered row to HBM (SURVEY.md 8d, no cache credit) while part "
-                            "of them is served by L2 / Infinity Cache; the counted fabric-side rate is frac_counter, and "
-                            "traffic / compulsory_bytes (refetch_factor) is the headroom a better row order could remove")
+                            "of them is served by L2 / Infinity Cache, so the 8 TB/s specification is not this kernel's "
+                            "ceiling; frac_of_gather_ceiling prices it against the measured random-row gather rate of this "
+                            "box, frac_counter is the counted fabric-side rate, refetch_factor = traffic / compulsory_bytes")
         if args.model == "lightgcn":
             # nominal traffic of a step that touches every row in every layer, for reference only: the
             # timed step reads less (rows the loss does not depend on / rows whose gradient is zero are not touched)
@@ -568,6 +637,7 @@ def main():
                "config": {"workload": f"{cfg_tag} {mname} L={L} D={D} users={nu} items={ni} "
                                       f"edges={ne} nnz={nnz} train_batch={B} adam lr=0.01 {cfg['norm_type']} {cfg['mul_loss_func']}",
                           "train_batch": B, "parallelism": f"{parallel}-shard x{world}" if sharded else "single",
+                          **({"parallelism_note": parallelism_note} if parallelism_note else {}),
                           "step": "loss -> backward -> Adam on one batch; same loss and gradients as the all-rows step: rows "
                                   "of the top two forward layers that the batch's loss does not read are not computed, "
                                   "backward products do not fetch operand rows that are exactly zero "
@@ -576,8 +646,106 @@ def main():
                                      "last backward product instead of a separate launch (--no-fused-adam separates them)"
                                      if (not args.no_fused_adam and getattr(model, "_fused_opt", None) is not None) else "")},
                "roofline": roof, "extra": extra}
-        if not args.no_cpu and world == 1 and args.model in ("lightgcn", "ngcf") and not sharded:
-            out["cpu_baseline"] = cpu_baseline(args, args.model, rp, col, val, n, nu, ni, epoch)
+        cpu_inputs = (rp, col, val, n, nu, ni, epoch) if (world == 1 and args.model in ("lightgcn", "ngcf") and not sharded) else None
+        del model, opt, prod
+        torch.cuda.empty_cache()
+        return out, cpu_inputs, ds
+    return None, None, ds
+
+
+def _leg_args(args, **kw):
+    import copy
+    a = copy.copy(args)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _compact(line):
+    """What extra.configs keeps of a leg's line: the figures and the rooflines, not the prose."""
+    keep = {k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype") if k in line}
+    keep["workload"] = line["config"]["workload"]
+    for rk in ("roofline", "roofline_mfma"):
+        r = line.get(rk)
+        if r:
+            keep[rk] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "mean_launch_ms", "launches_timed",
+                                          "frac_of_gather_ceiling", "frac_of_stream_triad", "frac_counter", "traffic",
+                                          "step_kernels_ms_per_step", "ms_all_rows_per_layer") if k in r}
+    return keep
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.model != "tgcn":
+        sys.exit(launch_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.model == "tgcn":
+        world, rank, local = 1, 0, 0
+    args.gpus = world
+    if args.share_gpu:
+        local = 0
+    assert torch.cuda.is_available(), "bench.py needs a GPU (tagrec_amd has no CPU path)"
+    if local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} GPU(s) are visible "
+                 "(one rank per GPU; --share-gpu for a rehearsal)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    sharded = (world > 1 or args.force_shard) and args.model != "tgcn"
+    if sharded:
+        import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if args.share_gpu and world > 1:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    # measured ceilings of this box (rank 0's GPU; every rank runs them so that the ranks stay in step)
+    ceilings = None if args.no_probes else probe_ceilings(dev)
+    if args.model == "tgcn":
+        print(json.dumps(bench_tgcn(args, ceilings)))
+        return
+    if args.parallel == "both" and sharded and args.model == "lightgcn":
+        # both partitions of the SAME problem in one job: the line is `auto`'s choice, the other one rides along
+        o_auto, cpu_inputs, ds = run_table_model(_leg_args(args, parallel="auto"), dev, rank, world, sharded, ceilings)
+        picked = "feature" if (rank != 0 or "feature" in o_auto["config"]["parallelism"]) else "row"
+        if world > 1:
+            t_ = torch.tensor([1 if picked == "feature" else 0], device=dev)
+            dist.broadcast(t_, 0)
+            picked = "feature" if int(t_) else "row"
+        other = "row" if picked == "feature" else "feature"
+        o_other, _, ds = run_table_model(_leg_args(args, parallel=other), dev, rank, world, sharded, ceilings, ds=ds, light=True)
+        out = o_auto
+        if rank == 0:
+            out["extra"]["partitions"] = {picked: {"ms_per_step": o_auto["ms_per_step"], "value": o_auto["value"]},
+                                          other: {**_compact(o_other), "collectives": o_other["extra"].get("collectives")}}
+    else:
+        if args.parallel == "both":
+            args.parallel = "auto"
+        out, cpu_inputs, ds = run_table_model(args, dev, rank, world, sharded, ceilings)
+    if rank == 0:
+        headline = (args.model == "lightgcn" and not sharded and args.scale == 1.0 and args.dim == 64 and args.layers == 3)
+        if headline and not args.no_extra_configs:
+            # the other single-GPU configurations of BASELINE.json, short legs in the same process so that the driver's
+            # clock covers them: C3 = NGCF on the same graph, C4 = TGCN on the tripartite graph
+            legs = {}
+            print("[bench] extra.configs: C3 NGCF leg ...", file=sys.stderr, flush=True)
+            c3, _, _ = run_table_model(_leg_args(args, model="ngcf", steps=10, warmup=3, big_batch=0), dev, 0, 1, False, ceilings,
+                                       ds=ds, light=True)
+            legs["C3"] = _compact(c3)
+            del ds
+            torch.cuda.empty_cache()
+            print("[bench] extra.configs: C4 TGCN leg ...", file=sys.stderr, flush=True)
+            legs["C4"] = _compact(bench_tgcn(_leg_args(args, model="tgcn", steps=3, warmup=1, dim=128), ceilings))
+            out["extra"]["configs"] = legs
+        ds = None
+        torch.cuda.empty_cache()
+        if not args.no_cpu and cpu_inputs is not None:
+            out["cpu_baseline"] = cpu_baseline(args, args.model, *cpu_inputs)
         else:
             out["cpu_baseline"] = ("not run (--no-cpu)" if args.no_cpu else
                                    "not run (timed on rank 0 of the 1-GPU configuration only)" if world > 1 or sharded else

@@ -111,6 +111,10 @@ int tagrec_spmm_normbwd_drop_f32(const tagrec_graph* g, const float* G_in, const
                                  const float* inv_norm, const float* dZ, float d_scale, float drop_p,
                                  uint64_t seed, float* G_out, int D, void* stream);
 int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream);
+/* The same mask on a compact row list: element (j, c) of x [n_rows, D] takes the draw of element (rows[j], c) of the full
+ * [N, D] layer output, so a node named by several list slots gets ONE mask (model/ngcf.py:85 drops the full output). */
+int tagrec_dropout_rows_f32(const float* x, float* out, const int64_t* rows, int64_t n_rows, int D, float p, uint64_t seed,
+                            void* stream);
 
 /* Backward layers on a ROW-SPARSE gradient.  The gradient that enters the backward chain is non-zero on the <= 3 B rows
  * of the batch only, and one hop later on their neighbours, so most rows a backward product would gather are zero.
@@ -428,6 +432,16 @@ int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, c
                             const float* wb, const float* out, const float* dOut, const float* dfeat, const float* dS,
                             int64_t n, int D, int Dout, int C, int V, float* result, float* workspace,
                             int64_t workspace_floats, void* stream);
+
+/* ---- bandwidth probes (measured ceilings of the box next to the 8 TB/s specification) ----------------
+ * a = b + s * c over n floats (stream triad; 12 bytes per element), and a random whole-row gather with the access shape
+ * of the SpMM's neighbour gather (64 rows of D floats per wavefront and index chunk, nothing else): sums of the gathered
+ * rows land in out[tagrec_probe_gather_out_floats()], which exists only to keep the loads alive.  Indices are NOT
+ * range-checked on the device: the caller guarantees 0 <= idx[i] < n_rows. */
+int tagrec_probe_triad_f32(float* a, const float* b, const float* c, float s, int64_t n, void* stream);
+int64_t tagrec_probe_gather_out_floats(void);
+int tagrec_probe_gather_rows_f32(const float* table, int64_t n_rows, int D, const int32_t* idx, int64_t n_idx, float* out,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

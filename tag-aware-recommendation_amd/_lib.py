@@ -97,6 +97,7 @@ _SIGNATURES = {
     "tagrec_spmm_normbwd_drop_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, ctypes.c_uint64, c_void_p,
                                      c_int, c_void_p],
     "tagrec_dropout_f32": [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p],
+    "tagrec_dropout_rows_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, ctypes.c_uint64, c_void_p],
     "tagrec_rownorm_bwd_flags_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int, c_int64, c_int, c_void_p,
                                      c_void_p, c_void_p],
     "tagrec_spmm_normbwd_sparse_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
@@ -123,6 +124,9 @@ _SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_spmm_axpy_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_float, c_float, c_float, c_float, c_int64, c_int, c_void_p],
+    "tagrec_probe_triad_f32": [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p],
+    "tagrec_probe_gather_out_floats": [],
+    "tagrec_probe_gather_rows_f32": [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_sum_n_f32": [c_void_p, c_void_p, c_int, c_int64, c_void_p],
     "tagrec_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int64,
                         c_void_p],
@@ -146,7 +150,7 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header and library disagree
         fn.argtypes = argtypes
-        fn.restype = c_int64 if name.endswith(("_workspace", "_result")) else c_int
+        fn.restype = c_int64 if name.endswith(("_workspace", "_result", "_floats")) else c_int
     lib.tagrec_last_error.argtypes = []
     lib.tagrec_last_error.restype = c_char_p
     if lib.tagrec_abi_version() != ABI_VERSION:

@@ -481,12 +481,27 @@ __global__ __launch_bounds__(kThreads) void adam_tail_kernel(float* __restrict__
 }
 
 // out = mask(seed) * x / (1 - p), the mask of common.h's DropMask (x may alias out)
-__global__ __launch_bounds__(kThreads) void dropout_kernel(const float4* __restrict__ x, float4* __restrict__ out, int64_t n4,
+__global__ __launch_bounds__(kThreads) void dropout_kernel(const float4* x, float4* out, int64_t n4,
                                                            DropMask m) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
     float4 v = x[i];
     drop4(m, i, v.x, v.y, v.z, v.w);
+    out[i] = v;
+  }
+}
+
+// The same mask on a COMPACT set of rows: element (j, c) of x [T, d] takes the draw of element (rows[j], c) of the full [N, d]
+// tensor, so every slot of a node that a row list names several times gets that node's mask (the reference draws one mask
+// per node: F.dropout on the full layer output, /root/reference/model/ngcf.py:85).
+__global__ __launch_bounds__(kThreads) void dropout_rows_kernel(const float4* x, float4* out,
+                                                                const int64_t* __restrict__ rows, int64_t T, int d4, DropMask m) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  const int64_t n4 = T * d4;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
+    const int64_t j = i / d4;
+    float4 v = x[i];
+    drop4(m, rows[j] * d4 + (i - j * d4), v.x, v.y, v.z, v.w);
     out[i] = v;
   }
 }
@@ -734,6 +749,21 @@ extern "C" int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p
   return TAGREC_OK;
 }
 
+extern "C" int tagrec_dropout_rows_f32(const float* x, float* out, const int64_t* rows, int64_t n_rows, int D, float p, uint64_t seed,
+                                       void* stream) {
+  TAGREC_REQUIRE(x && out && rows, "dropout_rows: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && D >= 4 && D % 4 == 0 && aligned16(x) && aligned16(out),
+                 "dropout_rows: need a width that is a multiple of 4 and 16-byte aligned buffers");
+  TAGREC_REQUIRE(p >= 0.f && p < 1.f, "dropout_rows: p must be in [0, 1)");
+  if (n_rows == 0) return TAGREC_OK;
+  int64_t blocks = (n_rows * (D / 4) + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  dropout_rows_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+      reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), rows, n_rows, D / 4, DropMask{p, seed});
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
 extern "C" int tagrec_row_flags_f32(const float* X, int64_t n_rows, int D, uint8_t* row_flags, unsigned* count, void* stream) {
   TAGREC_REQUIRE(X && row_flags && count, "row_flags: null pointer");
   TAGREC_REQUIRE(n_rows >= 0 && D >= 1, "row_flags: bad shape");
@@ -753,7 +783,7 @@ namespace tagrec {
 typedef float sum_f4 __attribute__((ext_vector_type(4)));
 struct SumSrcs { const sum_f4* p[8]; };
 template <int K>
-__global__ __launch_bounds__(256) void sum_n_kernel(SumSrcs s, sum_f4* __restrict__ out, int64_t n4) {
+__global__ __launch_bounds__(256) void sum_n_kernel(SumSrcs s, sum_f4* out, int64_t n4) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
     sum_f4 a = __builtin_nontemporal_load(s.p[0] + i);
@@ -762,7 +792,7 @@ __global__ __launch_bounds__(256) void sum_n_kernel(SumSrcs s, sum_f4* __restric
     out[i] = a;
   }
 }
-__global__ void sum_n_tail_kernel(SumSrcs s, int k, float* __restrict__ out, int64_t lo, int64_t n) {
+__global__ void sum_n_tail_kernel(SumSrcs s, int k, float* out, int64_t lo, int64_t n) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = lo + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     float a = reinterpret_cast<const float*>(s.p[0])[i];

@@ -776,6 +776,9 @@ int launch_spmm(const tagrec_graph* g, const float* X, const EpiArgs& e, int D, 
   }
   if (EPI == EPI_NORM_ACC && !e.accum)
     return fail(TAGREC_E_INVALID, std::string(who) + ": acc may be NULL only with the vector kernels (D in {8,...,256}, aligned rows)");
+  if (e.adam.p)       // the scalar kernel stores the raw gradient into e.Y == p and never touches m / v
+    return fail(TAGREC_E_INVALID, std::string(who) + ": the fused Adam epilogue needs the vector kernels (D in {8,...,256}, "
+                                                     "every operand 16-byte aligned)");
   if (e.row_mask || e.in_flags || e.out_flags || e.b_flags)
     return fail(TAGREC_E_INVALID, std::string(who) + ": row masks / row flags need the vector kernels (D in {8,...,256}, "
                                                      "every operand 16-byte aligned); the scalar kernel would ignore them");
@@ -892,7 +895,8 @@ extern "C" int tagrec_spmm_axpy_adam_f32(const tagrec_graph* g, const float* G_i
   TAGREC_REQUIRE(step >= 1, "spmm_axpy_adam: step counts from 1");
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_adam: D must be 8 .. 256, a power of two");
   TAGREC_REQUIRE(static_cast<const void*>(G_in) != static_cast<const void*>(p), "spmm_axpy_adam: the gathered operand aliases the parameters");
-  TAGREC_REQUIRE(aligned16(p) && aligned16(m) && aligned16(v), "spmm_axpy_adam: rows must be 16-byte aligned");
+  TAGREC_REQUIRE(aligned16(p) && aligned16(m) && aligned16(v) && aligned16(G_in) && aligned16(B),
+                 "spmm_axpy_adam: every operand (p, m, v, G_in, B) must be 16-byte aligned");
   const double bc1 = 1.0 - pow(static_cast<double>(b1), static_cast<double>(step));      // as tagrec_adam_f32
   const double bc2 = 1.0 - pow(static_cast<double>(b2), static_cast<double>(step));
   EpiArgs e{p, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, nullptr, b_flags};

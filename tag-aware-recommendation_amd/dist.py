@@ -34,6 +34,7 @@ import torch.distributed as dist
 from . import _lib, help as H
 from .graph import Graph
 from .lightgcn import xavier_tables
+from .train import fused_optimizer
 
 
 class HipOps:
@@ -463,13 +464,14 @@ class _ShardedLoss(torch.autograd.Function):
                                   dzf[r] if dzf is not None else None)
                     gat.put(c, gn[r], fo[r] if sparse else None)
                 operand = gat.result()
-            fused = getattr(m, "_fused_opt", None) if (restricted and m.reg == 0 and dzf is not None) else None
+            fused = fused_optimizer(m) if (restricted and m.reg == 0 and dzf is not None) else None
             if fused is not None:          # Adam in the epilogue of the last hop (Adam.fuse_into): no gradient tensor
                 am, av, step = fused.fused_state(m.table)
                 for c in range(part.n_chunks):
                     r = part.chunk_rows(c)
                     ops.last_hop_adam(m.graph_chunks[c], operand[0], operand[1], operand[2], d_out[r], s, dzf[r],
                                       m.table.data[r], am[r], av[r], fused.lr, fused.betas, fused.eps, step)
+                fused.fused_commit(m.table)
                 ctx.raws = ctx.invs = ctx.y_top = None
                 return None, None, None
             g0 = torch.empty_like(d_out)
@@ -1053,13 +1055,14 @@ class _FeatureRestrictedLoss(torch.autograd.Function):
             gn.index_add_(0, rows, nb[k])                  # (batch rows lie inside the mask: the product wrote them)
             fo.index_fill_(0, rows, 1)
             gcur, flags, count = gn, fo, None              # flags always consulted: a masked hop wrote its mask only
-        fused = getattr(m, "_fused_opt", None) if not reg else None
+        fused = fused_optimizer(m) if not reg else None
         if fused is not None:              # Adam in the epilogue of the last hop (Adam.fuse_into): no gradient tensor
             b = torch.empty(n, Dl, dtype=torch.float32, device=dev)             # the ego layer's share of the mean, batch rows
             b.index_fill_(0, rows, 0.0)
             b.index_add_(0, rows, dz)
             am, av, step = fused.fused_state(m.table)
             ops.last_hop_adam(m.graph, gcur, flags, count, b, 1.0, tflag, m.table.data, am, av, fused.lr, fused.betas, fused.eps, step)
+            fused.fused_commit(m.table)
             ctx.raws = ctx.at_rows = None
             return None, None, None
         g0 = torch.empty(n, Dl, dtype=torch.float32, device=dev)

@@ -205,16 +205,40 @@ def transe_loss(head_e, rela_e, pos_tail_e, neg_tail_e):
     return torch.nn.functional.softplus(ps - ns).mean()
 
 
-def message_drop(x, p, seed, out=None):
+def message_drop(x, p, seed, out=None, rows=None):
     """mask(seed) * x / (1 - p) with the library's counter-based mask (the one the fused layer kernels apply);
-    p = 0 returns x."""
+    p = 0 returns x.  rows (int64 [T], x is [T, d]): x holds rows `rows` of a full [N, d] tensor and element (j, c) takes
+    the draw of element (rows[j], c) of that tensor -- repeated ids get the same mask."""
     if p <= 0:
         return x
     x = x.contiguous()
     out = torch.empty_like(x) if out is None else out
+    if rows is not None:
+        _lib.check(_lib.load().tagrec_dropout_rows_f32(_lib.ptr(x), _lib.ptr(out), _lib.ptr(rows), x.shape[0], x.shape[1],
+                                                       float(p), int(seed), _lib.stream_ptr()), "dropout_rows")
+        return out
     _lib.check(_lib.load().tagrec_dropout_f32(_lib.ptr(x), _lib.ptr(out), x.numel(), float(p), int(seed), _lib.stream_ptr()),
                "dropout")
     return out
+
+
+class _MessageDrop(torch.autograd.Function):
+    """`message_drop` with its backward (the same mask on the gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return message_drop(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        return message_drop(g.contiguous(), ctx.p, ctx.seed), None, None
+
+
+def message_dropout(x, p, seed):
+    """F.dropout(x, p, training=True) with the library's counter-based mask (a function of seed and element index) instead
+    of torch's generator: differentiable, and reproducible by every other path that is handed the same seed."""
+    return x if p <= 0 else _MessageDrop.apply(x, float(p), int(seed))
 
 
 def node_drop(graph, keep_prob, training=False):

@@ -18,6 +18,7 @@ from . import _lib, help as H
 from .base import TableModel, xavier_tables  # noqa: F401  (xavier_tables re-exported)
 from .config import CFG as _GLOBAL_CFG
 from .graph import Graph, creat_adj
+from .train import fused_optimizer
 
 
 def _layer_seed(seed, k):
@@ -113,6 +114,7 @@ def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0, masks=Non
         table, opt = fused
         m, v, step = opt.fused_state(table)
         graph_t.spmm_axpy_adam(g, flags[cur], counts[cur:cur + 1], d_out, s, None, table.data, m, v, opt.lr, opt.betas, opt.eps, step)
+        opt.fused_commit(table)
         return None
     g0 = torch.empty_like(d_out)
     if sparse:
@@ -208,6 +210,7 @@ def restricted_backward(graph_t, rows, d_out_b, state, shape, fused=None):
         table, opt = fused
         m, v, step = opt.fused_state(table)
         graph_t.spmm_axpy_adam(g, flags, count, dz, s, tflag, table.data, m, v, opt.lr, opt.betas, opt.eps, step)
+        opt.fused_commit(table)
         return None
     g0 = torch.empty(n, D, dtype=torch.float32, device=dev)
     graph_t.spmm_axpy_sparse(g, flags, count, dz, s, g0, b_flags=tflag)
@@ -382,7 +385,7 @@ class LightGCN(TableModel):
         nu, ni = self.num_list[0], self.num_list[1]
         if self._fused_ok():
             drops, seed = self._drops()
-            fused = getattr(self, "_fused_opt", None) if (self.training and torch.is_grad_enabled()) else None
+            fused = fused_optimizer(self) if (self.training and torch.is_grad_enabled()) else None
             res = _PropagateBprLoss.apply(self.table, self._graph(), self.num_layer, nu, ni, batch_data,
                                           H.loss_kind_id(self.loss_func), self.reg != 0, drops, seed, self.restrict_forward,
                                           fused)

@@ -19,6 +19,7 @@ from . import _lib, help as H
 from .base import TableModel
 from .config import CFG as _GLOBAL_CFG
 from .graph import Graph, creat_adj
+from .train import fused_optimizer
 
 
 def dense_forward(nei, x, w1p, w2p, xp, inv, z_slot, ldz, row_mask=None):
@@ -68,23 +69,24 @@ def _layer_seed(seed, k):
     return (int(seed) * 64 + k) & 0xFFFFFFFFFFFFFFFF
 
 
-def _drop_renorm(xp, inv, z_slot, ldz, p, seed):
+def _drop_renorm(xp, inv, z_slot, ldz, p, seed, rows=None):
     """Message dropout of a layer's output (ngcf.py:85) behind the fused dense kernel: Xp <- mask(seed) Xp / (1 - p) with the
     library's counter-based mask, then the slot of the concatenated output and the inverse norms are recomputed from it
-    (two element-wise passes; the MFMA kernels stay in use)."""
-    H.message_drop(xp, p, seed, out=xp)
+    (two element-wise passes; the MFMA kernels stay in use).  rows: xp holds these rows of the layer output; the mask is
+    the full output's, keyed by node id (one mask per node however often a row list names it)."""
+    H.message_drop(xp, p, seed, out=xp, rows=rows)
     n, d = xp.shape
     _lib.check(_lib.load().tagrec_rownorm_fwd_f32(_lib.ptr(xp), _lib.ptr(z_slot), ldz, _lib.ptr(inv), n, d, _lib.stream_ptr()),
                "rownorm_fwd")
 
 
-def _dxp_through_dropout(dx_next, xp, inv, dz, ldz, p, seed):
+def _dxp_through_dropout(dx_next, xp, inv, dz, ldz, p, seed, rows=None):
     """d loss / d (pre-dropout Xp) = mask / (1 - p) * (dx_next + normalize-backward(Xp_dropped, inv, dz))."""
     n, d = xp.shape
     g = torch.zeros_like(xp) if dx_next is None else dx_next.contiguous().clone()
     _lib.check(_lib.load().tagrec_rownorm_bwd_f32(_lib.ptr(xp), _lib.ptr(inv), _lib.ptr(dz), ldz, 1.0, _lib.ptr(g), 1, n, d,
                                                   _lib.stream_ptr()), "rownorm_bwd")
-    return H.message_drop(g, p, seed, out=g)
+    return H.message_drop(g, p, seed, out=g, rows=rows)
 
 
 def propagate_forward(graph, x0, wps, dims, loss_rows=None, drops=None, seed=0):
@@ -123,8 +125,8 @@ def propagate_forward(graph, x0, wps, dims, loss_rows=None, drops=None, seed=0):
             zc = torch.empty(rows.numel(), d, dtype=torch.float32, device=x0.device)
             dense_forward(nc, xc, w1p, w2p, xpc, invc, zc, d)
             pk = drops[k] if drops else 0.0
-            if pk > 0:                                             # (the mask is indexed by the position in this row list)
-                _drop_renorm(xpc, invc, zc, d, pk, _layer_seed(seed, k))
+            if pk > 0:                      # the node's mask (keyed by node id): every slot of a repeated node is identical
+                _drop_renorm(xpc, invc, zc, d, pk, _layer_seed(seed, k), rows)
             out[:, off:off + d].index_copy_(0, rows, zc)          # the other rows of this slot are never read
             saved.append(("rows", (rows, first), masks[k], masks.get(k - 1), xc, nc, xpc, invc, w1p, w2p, pk, _layer_seed(seed, k)))
             break
@@ -154,7 +156,7 @@ def propagate_backward(graph_t, d_out, saved, dims):
             d = dims[k + 1]
             dzc = d_out[:, offs[k + 1]:offs[k + 1] + d].index_select(0, rows) * first[:, None]     # one slot per node
             if pk > 0:
-                d_nei_c, d_xd_c, dw1, dw2 = dense_backward(_dxp_through_dropout(None, xpc, invc, dzc, d, pk, sk), nc, xc, w1p, w2p)
+                d_nei_c, d_xd_c, dw1, dw2 = dense_backward(_dxp_through_dropout(None, xpc, invc, dzc, d, pk, sk, rows), nc, xc, w1p, w2p)
             else:
                 d_nei_c, d_xd_c, dw1, dw2 = dense_backward(None, nc, xc, w1p, w2p, norm=(xpc, invc, dzc, d))
             dws[k] = (dw1, dw2)
@@ -280,6 +282,7 @@ def restricted_backward(graph_t, rows, d_b, state, dims, n, fused=None):
             table, opt = fused
             m_, v_, step = opt.fused_state(table)
             graph_t.spmm_axpy_adam(g_in, in_flags, None, addend, 1.0, b_flags, table.data, m_, v_, opt.lr, opt.betas, opt.eps, step)
+            opt.fused_commit(table)
             return None
         out = torch.empty(n, dims[0], dtype=torch.float32, device=dev)
         if in_flags is None and b_flags is None:
@@ -481,7 +484,7 @@ class NGCF(TableModel):
         nu, ni = self.num_list[0], self.num_list[1]
         if self.agg_type == "bi_agg" and self._fused_ok():
             drops, seed = self._drops()
-            fused = getattr(self, "_fused_opt", None) if (self.training and torch.is_grad_enabled()) else None
+            fused = fused_optimizer(self) if (self.training and torch.is_grad_enabled()) else None
             res = _PropagateBprLoss.apply(self.norm_adj, tuple(self.dim_layer_list), nu, ni, batch_data,
                                           H.loss_kind_id(self.loss_func), drops, seed, fused, self.table, *self._mats())
             return res[0], self.reg * res[1]

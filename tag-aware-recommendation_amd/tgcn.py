@@ -26,6 +26,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from . import _lib, help as H
+from . import tgcn_step as TS
 from .config import CFG as _GLOBAL_CFG
 from .graph import Graph
 
@@ -649,20 +650,39 @@ class TGCN(nn.Module):
         self.use_checkpoint = config.get("tgcn_checkpoint", True)
         self.fused_dense = config.get("tgcn_fused_dense", True)
         self.pull_backward = config.get("tgcn_pull_backward", True)
+        self.step_node = config.get("tgcn_step_node", True)     # loss(): the restricted step as one hand-derived node
+
+    def _step_node_ok(self):
+        d = self.dim_layer_list
+        return self.fused_dense and all(fused_dense_supported(d[i], d[i + 1], self.dim_atten, self.num_bit_conv, self.num_vec_conv)
+                                        for i in range(self.num_layer))
 
     def train(self, mode=True):
         self._eval_cache = None
         return super().train(mode)
 
+    def _drops(self):
+        """(per-layer drop rates, seed of this pass) when message dropout is active (tgcn.py:217-219), else (None, 0): the
+        library's counter-based masks, a function of (seed, layer, node type, node id, column); a new seed per
+        training-mode pass.  Parity with the reference in training mode is statistical (it draws torch's generator)."""
+        drops = [float(p) for p in self.message_drop_list[:self.num_layer]]
+        if not (self.training and any(p > 0 for p in drops)):
+            return None, 0
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TagrecError("TGCN: message dropout draws a new seed on the host every step and cannot be captured")
+        self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+        return tuple(drops + [0.0] * (self.num_layer - len(drops))), (int(self.seed) << 24) + self._drop_calls
+
     def forward(self):
         eu, ei, et, ew = self.embed["user"], self.embed["item"], self.embed["tag"], self.embed["weight"]
         ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])          # index 0 = pad (tgcn.py:21-24)
         cu, ci, ct = [eu], [ei], [et]
+        drops, seed = self._drops()
         for i, layer in enumerate(self.layer.values()):
             eu, ei, et = layer(eu, ei, et, ewp, self.nbr, self.chunk_rows, self.use_checkpoint, self.fused_dense, self.inv)
-            p = self.message_drop_list[i]
-            if self.training and p > 0:
-                eu, ei, et = (torch.nn.functional.dropout(t, p=p, training=True) for t in (eu, ei, et))
+            if drops and drops[i] > 0:
+                eu, ei, et = (H.message_dropout(x.contiguous(), drops[i], TS._drop_seed(seed, i, t))
+                              for x, t in ((eu, "user"), (ei, "item"), (et, "tag")))
             cu.append(H.normalize_rows(eu))
             ci.append(H.normalize_rows(ei))
             ct.append(H.normalize_rows(et))
@@ -751,7 +771,15 @@ class TGCN(nn.Module):
 
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()
-        if self.prune_forward and self.training and not torch.cuda.is_current_stream_capturing():
+        restricted = self.prune_forward and self.training and not torch.cuda.is_current_stream_capturing()
+        if restricted and self.step_node and torch.is_grad_enabled() and self._step_node_ok():
+            # the whole step as one hand-derived autograd node (tgcn_step.py)
+            drops, seed = self._drops()
+            flat = [p for k in range(self.num_layer) for p in TS.layer_params(self.layer[str(k)])]
+            res = TS.TgcnBprLoss.apply(self, batch_data, drops, seed, self.embed["user"], self.embed["item"], self.embed["tag"],
+                                       self.embed["weight"], *flat)
+            return res[0], self.reg * res[1]
+        if restricted:
             all_users, all_items, batch_data = self._forward_rows(batch_data)
         else:
             all_users, all_items = self.forward()[:2]

@@ -1,0 +1,421 @@
+"""The TGCN training step as ONE hand-derived autograd node (/root/reference/model/tgcn.py:108-137, 204-249).
+
+`TGCN.loss(batch)` in training mode: (embedding tables, every layer's parameters) -> [mul_loss, l2reg_loss] with the
+forward pass and the whole backward pass written out by hand over the library's kernels, as `_PropagateBprLoss` is for
+LightGCN / NGCF.  What the autograd-composed form paid for and this one does not: pairwise accumulation of the gradients
+of every tensor with several readers (154 element-wise adds per step at C4), `zeros_like().index_copy_()` to lift row-subset
+gradients back to table size, the zero-filled full-size gradients of column slices, host round trips to find non-zero rows.
+
+Structure of a step (bounded fan-in is what makes it pay: k sampled neighbours per node and relation):
+  * `TGCN._needed_rows`: layer l is computed on the rows the batch's loss depends on -- the <= 3 B batch rows at the top, their
+    2 k neighbours per row one layer down, ... -- on COMPACT tables (a layer's output holds only those rows, in ascending
+    node order; neighbour ids are renumbered into it through a position map);
+  * forward per layer: Q = X W2 on every input row, P = X[self rows] W1[:D] + b, the six neighbour attentions
+    (csrc/tgcn.hip), the fused type-attention / convolution / fusion block (csrc/tgcn_fuse.hip) per node type;
+  * the loss reads [ego | normalize(layer 1) | ... | normalize(layer L)] at the batch rows (compact BPR kernels);
+  * backward per layer, top down: fused block (input gradients + its weight gradients), attention backward per relation
+    (dP, dWT, dv written; dQ and dEj PULLED over the relation's inverted table, the second relation of a neighbour type
+    adding the first one's result in the product's epilogue), then dX = dEj + dQ W2^T (+ the self rows' dXs = dT_self +
+    dP W1[:D]^T at their positions) -- every gradient buffer is written once where it is formed.
+
+Same loss and gradients as the all-rows pass (`TGCN.forward()` + triplet loss + autograd): tests/test_gpu_tgcn.py.
+"""
+import torch
+
+from . import _lib, help as H
+
+TYPES = ("user", "item", "tag")
+RELATIONS = (("user", "item"), ("user", "tag"), ("item", "user"), ("item", "tag"), ("tag", "user"), ("tag", "item"))
+OTHERS = {"user": ("item", "tag"), "item": ("user", "tag"), "tag": ("user", "item")}
+# slot of the neighbour type's vector inside a node's (user-side, item-side, tag-side) triple
+SLOT = {"user": 0, "item": 1, "tag": 2}
+
+
+def layer_params(layer):
+    """The parameters of one `_Layer` in the order the step's autograd node takes / returns them."""
+    ps = []
+    for t in TYPES:
+        a = layer.atten1[t]
+        ps += [a.W_1, a.W_2, a.b, a.v]
+    ps += [layer.U, layer.q, layer.p, layer.conv["bit_level"].weight, layer.conv["vec_level"]["conv_1"].weight,
+           layer.conv["vec_level"]["conv_2"].weight, layer.conv["vec_level"]["conv_3"].weight, layer.Wf, layer.bf]
+    return ps
+
+
+N_LAYER_PARAMS = 21
+
+
+def _drop_seed(seed, layer, t):
+    return (int(seed) * 64 + 3 * layer + SLOT[t]) & 0xFFFFFFFFFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------ raw kernel calls
+def attn_fwd(P, Q, WT, v, Ej, idx, widx):
+    from . import tgcn as TG
+    n, A = P.shape
+    k, D = idx.shape[1], Ej.shape[1]
+    attn = torch.empty(n, k, dtype=torch.float32, device=P.device)
+    out = torch.empty(n, D, dtype=torch.float32, device=P.device)
+    _lib.check(TG._timed("attn_fwd", _lib.load().tagrec_tgcn_attn_fwd_f32, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v),
+                         _lib.ptr(Ej), _lib.ptr(idx), _lib.ptr(widx), n, k, D, A, _lib.ptr(attn), _lib.ptr(out),
+                         _lib.stream_ptr()), "tgcn_attn_fwd")
+    return out, attn
+
+
+def attn_bwd(P, Q, WT, v, Ej, idx, widx, attn, d_out, dQ, dEj, dh):
+    """dP, dWT, dv written; pull form (dh [n k, A] written) or scatter form (float atomics into dQ / dEj)."""
+    from . import tgcn as TG
+    lib = _lib.load()
+    n, A = P.shape
+    k, D, n_wt = idx.shape[1], Ej.shape[1], WT.shape[0]
+    dP = torch.empty_like(P)
+    dWT, dv = torch.empty_like(WT), torch.empty_like(v)
+    ws_n = lib.tagrec_tgcn_attn_workspace(n_wt, A)
+    ws = torch.empty(ws_n, dtype=torch.float32, device=P.device)
+    _lib.check(TG._timed("attn_bwd", lib.tagrec_tgcn_attn_bwd_f32, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v),
+                         _lib.ptr(Ej), _lib.ptr(idx), _lib.ptr(widx), _lib.ptr(attn), _lib.ptr(d_out), n, k, D, A, n_wt,
+                         _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dEj), _lib.ptr(dh), _lib.ptr(dWT), _lib.ptr(dv), _lib.ptr(ws), ws_n,
+                         _lib.stream_ptr()), "tgcn_attn_bwd")
+    return dP, dWT, dv
+
+
+def fuse_fwd(t0, t1, t2, dp):
+    from . import tgcn as TG
+    U, q, p, wb, w1, w2, w3, Wf, bf = dp
+    n, D = t0.shape
+    out = torch.empty(n, Wf.shape[1], dtype=torch.float32, device=t0.device)
+    bw = torch.empty(n, 3, dtype=torch.float32, device=t0.device)
+    _lib.check(TG._timed("fuse_fwd", _lib.load().tagrec_tgcn_fuse_fwd_f32, _lib.ptr(t0), _lib.ptr(t1), _lib.ptr(t2), n, D,
+                         Wf.shape[1], U.shape[1], wb.shape[0], w1.shape[0], *[_lib.ptr(a) for a in dp], _lib.ptr(bw),
+                         _lib.ptr(out), _lib.stream_ptr()), "tgcn_fuse_fwd")
+    return out, bw
+
+
+def _dense_views(ps):
+    """(U, q, p, wb [C,3], w1 [V,D], w2 [V,2D], w3 [V,3D], Wf, bf) as the fused kernels take them."""
+    U, q, p, wb, w1, w2, w3, Wf, bf = ps
+    return (U.contiguous(), q.reshape(-1).contiguous(), p.reshape(-1).contiguous(), wb.reshape(wb.shape[0], 3).contiguous(),
+            w1.reshape(w1.shape[0], -1).contiguous(), w2.reshape(w2.shape[0], -1).contiguous(),
+            w3.reshape(w3.shape[0], -1).contiguous(), Wf.contiguous(), bf.reshape(-1).contiguous())
+
+
+def tall_wgrad(X, dY):
+    """X^T dY for X [n, d], dY [n, a] with n in the millions: slab products + one sum (see tgcn._TallMM)."""
+    n = X.shape[0]
+    if n < 65536:
+        return X.t() @ dY
+    S = 256
+    m = n // S * S
+    dW = torch.bmm(X[:m].view(S, m // S, -1).transpose(1, 2), dY[:m].view(S, m // S, -1)).sum(0)
+    if m < n:
+        dW = dW + X[m:].t() @ dY[m:]
+    return dW
+
+
+# ------------------------------------------------------------------------------------------------ the step
+def step_forward(model, batch, embs, ew, layers_ps, training_drop):
+    """Forward of the restricted step.  embs: {type: table}; layers_ps: per layer the 21 detached parameters.
+    Returns (res [2], state)."""
+    from . import tgcn as TG
+    dev = batch.device
+    lib = _lib.load()
+    need = model._needed_rows(batch)
+    sizes = {"user": model.num_user, "item": model.num_item, "tag": model.num_tag}
+    L = len(layers_ps)
+    ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])
+    top = need[L]
+    n_top = {t: top[t].numel() for t in ("user", "item")}
+    dims = model.dim_layer_list
+    dtot = sum(dims)
+    cat = {t: torch.empty(n_top[t], dtot, dtype=torch.float32, device=dev) for t in ("user", "item")}
+    for t in cat:
+        cat[t][:, :dims[0]] = embs[t].index_select(0, top[t])
+    X = dict(embs)
+    rows_in = {t: None for t in TYPES}
+    pos_in = {t: None for t in TYPES}
+    saved = []
+    off = dims[0]
+    drops, seed = training_drop
+    for li, ps in enumerate(layers_ps):
+        layer = model.layer[str(li)]
+        D, A = layer.in_features, layer.U.shape[1]
+        att = {t: ps[4 * i:4 * i + 4] for i, t in enumerate(TYPES)}          # W_1, W_2, b, v
+        dp = _dense_views(ps[12:])
+        rows_out = need[li + 1]
+        st = {"rows_out": rows_out, "rows_in": rows_in, "X": X, "att": att, "dp": dp, "ewp": ewp}
+        sel, Xs, Q, P = {}, {}, {}, {}
+        for t, (n1, n2) in OTHERS.items():
+            if rows_out[t] is None:
+                sel[t], Xs[t] = None, X[t]
+            else:
+                sel[t] = rows_out[t] if rows_in[t] is None else pos_in[t].index_select(0, rows_out[t] + 1).long() - 1
+                Xs[t] = X[t].index_select(0, sel[t])
+            Q[t] = X[t] @ att[t][1]
+            P[(t, n1)] = torch.addmm(att[n1][2], Xs[t], att[n1][0][:D])
+            P[(t, n2)] = torch.addmm(att[n2][2], Xs[t], att[n2][0][:D])
+        WT = {t: ewp @ att[t][0][D:] for t in TYPES}
+        st.update(sel=sel, Xs=Xs, Q=Q, P=P, WT=WT)
+        outs, attns, idxs = {}, {}, {}
+        for r, (src, nb) in enumerate(RELATIONS):
+            rows = rows_out[src]
+            m = Xs[src].shape[0]
+            if m == 0:
+                outs[r] = X[nb].new_zeros(0, D)
+                continue
+            idx = model.nbr[r][0] if rows is None else model.nbr[r][0].index_select(0, rows)
+            widx = model.nbr[r][1] if rows is None else model.nbr[r][1].index_select(0, rows)
+            if rows_in[nb] is not None:                      # neighbour ids -> positions in the compact table
+                idx = pos_in[nb].index_select(0, idx.flatten().long()).reshape(idx.shape)
+            outs[r], attns[r] = attn_fwd(P[(src, nb)], Q[nb], WT[nb], att[nb][3].reshape(-1), X[nb], idx, widx)
+            idxs[r] = (idx, widx)
+        st.update(outs=outs, attns=attns, idxs=idxs)
+        trips = {"user": (Xs["user"], outs[0], outs[1]), "item": (outs[2], Xs["item"], outs[3]),
+                 "tag": (outs[4], outs[5], Xs["tag"])}
+        O, BW = {}, {}
+        for t, trip in trips.items():
+            if trip[0].shape[0] > 0:
+                O[t], BW[t] = fuse_fwd(trip[0].contiguous(), trip[1], trip[2], dp)
+            else:
+                O[t], BW[t] = trip[0].new_zeros(0, dp[7].shape[1]), None
+        st.update(O=O, BW=BW)
+        # message dropout of the layer's outputs (tgcn.py:217-219): the library's counter-based mask keyed by NODE id
+        pk = drops[li] if drops else 0.0
+        Od = O
+        if pk > 0:
+            Od = {}
+            for t in TYPES:
+                if O[t].shape[0] == 0:
+                    Od[t] = O[t]
+                elif rows_out[t] is None:
+                    Od[t] = H.message_drop(O[t], pk, _drop_seed(seed, li, t))
+                else:
+                    Od[t] = H.message_drop(O[t], pk, _drop_seed(seed, li, t), rows=rows_out[t])
+        st["pk"] = pk
+        # positions of the batch rows in this layer's output, their normalised rows into the concat buffer
+        pos_out, extra = {}, {}
+        for t in TYPES:
+            pos_out[t] = None
+            if rows_out[t] is not None:
+                pos_out[t] = torch.zeros(sizes[t] + 1, dtype=torch.int32, device=dev)
+                pos_out[t][rows_out[t] + 1] = torch.arange(1, rows_out[t].numel() + 1, dtype=torch.int32, device=dev)
+        d_out = dims[li + 1]
+        norm_saved = {}
+        for t in cat:
+            extra[t] = top[t] if rows_out[t] is None else pos_out[t].index_select(0, top[t] + 1).long() - 1
+            xr = Od[t].index_select(0, extra[t])
+            inv = torch.empty(n_top[t], dtype=torch.float32, device=dev)
+            if n_top[t]:
+                _lib.check(lib.tagrec_rownorm_fwd_f32(_lib.ptr(xr), _lib.ptr(cat[t][:, off:]), dtot, _lib.ptr(inv), n_top[t], d_out,
+                                                      _lib.stream_ptr()), "rownorm_fwd")
+            norm_saved[t] = (xr, inv)
+        st.update(extra=extra, norm=norm_saved, off=off)
+        saved.append(st)
+        off += d_out
+        X, rows_in, pos_in = Od, rows_out, pos_out
+    B = batch.shape[0]
+    trip = torch.stack([torch.searchsorted(top["user"], batch[:, 0].contiguous()),
+                        torch.searchsorted(top["item"], batch[:, 1].contiguous()),
+                        torch.searchsorted(top["item"], batch[:, 2].contiguous())], dim=1).contiguous()
+    coef = torch.empty(B, dtype=torch.float32, device=dev)
+    partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=dev)
+    res = torch.empty(2, dtype=torch.float32, device=dev)
+    U, I = cat["user"], cat["item"]
+    _lib.check(lib.tagrec_bpr_fwd_f32(_lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(trip), B,
+                                      H.loss_kind_id(model.loss_func), _lib.ptr(coef), _lib.ptr(partials), _lib.ptr(res),
+                                      _lib.stream_ptr()), "bpr_fwd")
+    return res, {"saved": saved, "cat": cat, "trip": trip, "coef": coef, "top": top, "dims": dims, "sizes": sizes,
+                 "seed": seed}
+
+
+def step_backward(model, g, state, n_weight):
+    """Gradients of (embed.user, embed.item, embed.tag, embed.weight, 21 parameters per layer)."""
+    from . import tgcn as TG
+    lib = _lib.load()
+    saved, cat, trip, coef, top, dims = (state[k] for k in ("saved", "cat", "trip", "coef", "top", "dims"))
+    dev = trip.device
+    dtot = sum(dims)
+    B = trip.shape[0]
+    d_cat = {t: torch.zeros_like(cat[t]) for t in cat}
+    U, I, dU, dI = cat["user"], cat["item"], d_cat["user"], d_cat["item"]
+    _lib.check(lib.tagrec_bpr_bwd_f32(_lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(U), _lib.ptr(I), dtot, dtot, _lib.ptr(trip), B,
+                                      _lib.ptr(coef), _lib.ptr(g.contiguous()), 1.0, _lib.ptr(dU), _lib.ptr(dI), _lib.ptr(dU),
+                                      _lib.ptr(dI), _lib.stream_ptr()), "bpr_bwd")
+    L = len(saved)
+    layer_grads = [None] * L
+    d_ewp = None
+    G = None                  # {type: gradient w.r.t. the output rows of the layer being processed}
+    for li in range(L - 1, -1, -1):
+        st = saved[li]
+        layer = model.layer[str(li)]
+        D, A = layer.in_features, layer.U.shape[1]
+        att, dp, ewp = st["att"], st["dp"], st["ewp"]
+        rows_out, rows_in, X, Xs, sel = st["rows_out"], st["rows_in"], st["X"], st["Xs"], st["sel"]
+        O, pk = st["O"], st["pk"]
+        # gradient w.r.t. the (dropped) output rows: what the layer above sent down + the loss's normalised batch rows
+        Gd = {}
+        for t in TYPES:
+            m = O[t].shape[0]
+            gt = G[t] if (G is not None and G.get(t) is not None) else None
+            if t in cat and m > 0 and cat[t].shape[0] > 0:
+                xr, inv = st["norm"][t]
+                nb_rows = xr.shape[0]
+                dz = torch.empty_like(xr)
+                _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(xr), _lib.ptr(inv), _lib.ptr(d_cat[t][:, st["off"]:]), dtot, 1.0,
+                                                      _lib.ptr(dz), 0, nb_rows, xr.shape[1], _lib.stream_ptr()), "rownorm_bwd")
+                if gt is None:
+                    if nb_rows == m:              # the top layer: its rows ARE the batch rows, in order
+                        gt = dz
+                    else:
+                        gt = torch.zeros(m, xr.shape[1], dtype=torch.float32, device=dev)
+                        gt.index_add_(0, st["extra"][t], dz)
+                else:
+                    gt.index_add_(0, st["extra"][t], dz)
+            if gt is None:
+                gt = torch.zeros(m, dims[li + 1], dtype=torch.float32, device=dev)
+            if pk > 0 and m > 0:                  # through the dropout mask (same mask as the forward's)
+                gt = gt.contiguous()
+                H.message_drop(gt, pk, _drop_seed(state["seed"], li, t), out=gt, rows=rows_out[t])
+            Gd[t] = gt
+        # ---- fused dense block: input gradients per type, weight gradients summed over the three types
+        trips = {"user": (Xs["user"], st["outs"][0], st["outs"][1]), "item": (st["outs"][2], Xs["item"], st["outs"][3]),
+                 "tag": (st["outs"][4], st["outs"][5], Xs["tag"])}
+        dts, dense_g = {}, None
+        for t, tr in trips.items():
+            if tr[0].shape[0] == 0:
+                continue
+            r = TG._FusedDense._backward_rows(tr[0].contiguous(), tr[1], tr[2], *dp[:8], O[t], st["BW"][t], Gd[t].contiguous())
+            dts[t] = r[:3]
+            dense_g = list(r[3:12]) if dense_g is None else [a + b for a, b in zip(dense_g, r[3:12])]
+        if dense_g is None:
+            dense_g = [torch.zeros_like(x) for x in dp]
+        # ---- neighbour attentions: scatter-form relations first (into zeroed buffers), then the pull-form ones, each adding
+        # what has been collected so far in its product's epilogue
+        accX = {t: None for t in TYPES}
+        accQ = {t: None for t in TYPES}
+        dP = {}
+        dW1 = {t: torch.zeros_like(att[t][0]) for t in TYPES}
+        db = {t: torch.zeros_like(att[t][2]) for t in TYPES}
+        dv = {t: torch.zeros_like(att[t][3]) for t in TYPES}
+        dWTs = {t: None for t in TYPES}
+        n_in = {t: X[t].shape[0] for t in TYPES}
+        order = sorted(range(6), key=lambda r: (Xs[RELATIONS[r][0]].shape[0] >= TG._PULL_MIN_ROWS, r))
+        for r in order:
+            src, nb = RELATIONS[r]
+            m = Xs[src].shape[0]
+            if m == 0:
+                continue
+            d_out = dts[src][SLOT[nb]]
+            idx, widx = st["idxs"][r]
+            pull = m >= TG._PULL_MIN_ROWS
+            k = idx.shape[1]
+            if pull:
+                dh = torch.empty(m * k, A, dtype=torch.float32, device=dev)
+                dQ = dEj = None
+            else:
+                dh = None
+                if accX[nb] is None:
+                    accX[nb] = torch.zeros(n_in[nb], D, dtype=torch.float32, device=dev)
+                if accQ[nb] is None:
+                    accQ[nb] = torch.zeros(n_in[nb], A, dtype=torch.float32, device=dev)
+                dQ, dEj = accQ[nb], accX[nb]
+            dP[r], dWT_r, dv_r = attn_bwd(st["P"][(src, nb)], st["Q"][nb], st["WT"][nb], att[nb][3].reshape(-1), X[nb], idx, widx,
+                                          st["attns"][r], d_out, dQ, dEj, dh)
+            dWTs[nb] = dWT_r if dWTs[nb] is None else dWTs[nb] + dWT_r
+            dv[nb] = dv[nb] + dv_r.reshape(dv[nb].shape)
+            if pull:
+                accQ[nb], accX[nb] = _pull_add(idx, st["attns"][r], d_out, dh, n_in[nb], accQ[nb], accX[nb])
+        # ---- projections backward
+        dXout = {}
+        for t, (n1, n2) in OTHERS.items():
+            r1, r2 = RELATIONS.index((t, n1)), RELATIONS.index((t, n2))
+            dXs = None
+            if t in dts:
+                dXs = dts[t][SLOT[t]]
+                for r_, n_ in ((r1, n1), (r2, n2)):
+                    dXs.addmm_(dP[r_], att[n_][0][:D].t())
+                    dW1[n_][:D] += tall_wgrad(Xs[t], dP[r_])
+                    db[n_] += dP[r_].sum(0, keepdim=True)
+            dx = accX[t]
+            if accQ[t] is not None:
+                if dx is None:
+                    dx = accQ[t] @ att[t][1].t()
+                else:
+                    dx.addmm_(accQ[t], att[t][1].t())
+                dW2 = tall_wgrad(X[t], accQ[t])
+            else:
+                dW2 = torch.zeros_like(att[t][1])
+            if dx is None:
+                dx = torch.zeros(n_in[t], D, dtype=torch.float32, device=dev)
+            if dXs is not None:
+                if sel[t] is None:
+                    dx += dXs
+                else:
+                    dx.index_add_(0, sel[t], dXs)
+            dXout[t] = dx
+            st["dW2_" + t] = dW2
+            if dWTs[t] is not None:
+                dW1[t][D:] += ewp.t() @ dWTs[t]
+                contrib = dWTs[t] @ att[t][0][D:].t()
+                d_ewp = contrib if d_ewp is None else d_ewp + contrib
+        lg = []
+        for t in TYPES:
+            lg += [dW1[t], st["dW2_" + t], db[t], dv[t]]
+        U_, q_, p_, wb_, w1_, w2_, w3_, Wf_, bf_ = dense_g
+        shapes = [x.shape for x in layer_params(layer)[12:]]
+        lg += [x.reshape(s) for x, s in zip((U_, q_, p_, wb_, w1_, w2_, w3_, Wf_, bf_), shapes)]
+        layer_grads[li] = lg
+        saved[li] = None
+        G = dXout
+    # embedding tables: layer 0's input gradient + the ego slot of the concat at the batch rows
+    for t in cat:
+        if cat[t].shape[0]:
+            G[t].index_add_(0, top[t], d_cat[t][:, :dims[0]])
+    d_weight = d_ewp[1:] if d_ewp is not None else torch.zeros(n_weight, model.dim_weight, device=dev)
+    flat = [G["user"], G["item"], G["tag"], d_weight]
+    for lg in layer_grads:
+        flat += lg
+    return flat
+
+
+def _pull_add(idxc, attnc, doc, dh, n_dst, addQ, addX):
+    """(addQ + S dh, addX + G dOut) over the relation's table inverted on the spot (one radix sort of the n k neighbour
+    ids; pad slots sort behind the last destination row and are never read); add* may be None."""
+    from .graph import Graph
+    nc, k = idxc.shape
+    flat = idxc.flatten()
+    key = torch.where(flat > 0, flat - 1, n_dst)
+    skey, order = torch.sort(key, stable=True)
+    rowptr = torch.searchsorted(skey, torch.arange(n_dst + 1, dtype=skey.dtype, device=skey.device))
+    Gm = Graph(rowptr, torch.div(order, k, rounding_mode="floor").to(torch.int32), attnc.flatten().index_select(0, order),
+               (n_dst, nc), workspace=True)
+    Sm = Gm.like(order.to(torch.int32), torch.ones_like(Gm.val), nc * k)
+    if addQ is None:
+        outQ = Sm.spmm(dh)
+    else:
+        outQ = torch.empty_like(addQ)
+        Sm.spmm_axpy(dh, addQ, 1.0, outQ)
+    if addX is None:
+        outX = Gm.spmm(doc)
+    else:
+        outX = torch.empty_like(addX)
+        Gm.spmm_axpy(doc, addX, 1.0, outX)
+    return outQ, outX
+
+
+class TgcnBprLoss(torch.autograd.Function):
+    """(embedding tables, layer parameters) -> [mul_loss, l2reg_loss (unweighted)] for one BPR batch."""
+
+    @staticmethod
+    def forward(ctx, model, batch, drops, seed, eu, ei, et, ew, *flat):
+        n_l = len(model.layer)
+        layers_ps = [[p.detach() for p in flat[N_LAYER_PARAMS * i:N_LAYER_PARAMS * (i + 1)]] for i in range(n_l)]
+        embs = {"user": eu.detach(), "item": ei.detach(), "tag": et.detach()}
+        res, state = step_forward(model, batch, embs, ew.detach(), layers_ps, (drops, seed))
+        ctx.model, ctx.state, ctx.n_weight = model, state, ew.shape[0]
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = step_backward(ctx.model, g, ctx.state, ctx.n_weight)
+        ctx.state = None
+        return (None, None, None, None, *grads)

@@ -33,28 +33,43 @@ class Adam:
         self.step_count = 0
         self.capturable = bool(capturable)
         self._fused_done = set()          # parameters whose update of the current step was applied inside backward()
+        for p in self.params:             # the newest optimizer built over a parameter owns it: a fusion set up by an
+            p._tagrec_owner = self        # earlier one is revoked (`fused_optimizer`), the model hands out gradients again
 
     def fuse_into(self, model):
         """Let `model` apply this optimizer's update of its embedding table inside the last kernel of its backward pass
         (the gradient row is consumed where it is formed: no gradient tensor, no separate Adam launch over the table).
         The zero_grad() / backward() / step() protocol of basic_train.py:19-25 is unchanged: step() then only counts
         the step for that parameter.  One backward() per step(); not available with capturable=True.  Models without
-        the hook ignore the call."""
+        the hook ignore the call.
+
+        CONTRACT: with the fusion on, a training-mode backward() of `model.loss` CHANGES the table (and exp_avg /
+        exp_avg_sq) -- also one that is not followed by step() (gradient inspection, clipping); a second such
+        backward() before step() raises.  Use an un-fused optimizer for anything but the plain loop."""
         if self.capturable:
             raise _lib.TagrecError("Adam.fuse_into: the fused update keeps its step counter on the host (capturable=False)")
         if hasattr(model, "set_fused_optimizer"):
+            table = getattr(model, "table", None)
+            if table is not None and not any(q is table for q in self.params):
+                raise _lib.TagrecError("Adam.fuse_into: the model's table is not one of this optimizer's parameters")
+            if table is not None:
+                table._tagrec_owner = self
             model.set_fused_optimizer(self)
         return self
 
     def fused_state(self, p):
-        """(m, v, step number of the update about to be applied) for a parameter updated inside backward()."""
+        """(m, v, step number of the update about to be applied) for a parameter updated inside backward().  The caller
+        launches the update and then calls `fused_commit(p)`: a launch that fails leaves no sticky mark."""
         if id(p) in self._fused_done:
             raise _lib.TagrecError("Adam: a second backward() before step() with a fused update")
         st = self.state.get(id(p))
         if st is None:
             st = self.state[id(p)] = {"m": torch.zeros_like(p.data), "v": torch.zeros_like(p.data), "t": 0}
-        self._fused_done.add(id(p))
         return st["m"], st["v"], st["t"] + 1
+
+    def fused_commit(self, p):
+        """The fused update of `p` has been launched: step() only counts the step for it."""
+        self._fused_done.add(id(p))
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -105,6 +120,19 @@ class Adam:
                 if self.capturable:
                     st["t_dev"] = torch.zeros(1, dtype=torch.int64, device=p.device)
                     st["coef"] = torch.zeros(2, dtype=torch.float32, device=p.device)
+
+
+def fused_optimizer(model):
+    """The optimizer whose update of `model.table` runs inside the model's backward pass (`Adam.fuse_into`), or None:
+    the fusion is live only while that optimizer is still the newest one built over the table -- a second optimizer
+    created for the same model (new run, new lr) revokes it instead of leaving the old one updating behind its back."""
+    opt = getattr(model, "_fused_opt", None)
+    if opt is None:
+        return None
+    if getattr(getattr(model, "table", None), "_tagrec_owner", None) is not opt:
+        model._fused_opt = None
+        return None
+    return opt
 
 
 def _step(loss_func, opt, data):

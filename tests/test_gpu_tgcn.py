@@ -459,6 +459,37 @@ def test_pruned_and_row_sparse_step_equals_full_step_at_mid_scale():
         assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 2e-6 * top, k
 
 
+def test_step_node_with_message_dropout_equals_all_rows_pass():
+    """Message dropout (tgcn.py:217-219) in the hand-derived step node: the mask of a layer output is the library's
+    counter-based one keyed by (seed, layer, node type, NODE id, column), so the restricted step on compact tables and the
+    all-rows pass (`forward()` + autograd) handed the same seed drop the same elements: same loss, same gradients."""
+    ds = T.synth.make_tripartite_device(50_000, 50_000, 100_000, 3_000_000, seed=6, device=DEV)
+    cfg = T.get_config("tgcn", dim_latent=64, dim_layer_list=[64, 64, 64], device=DEV, train_batch=256, neighbor_k=25, reg=1e-4,
+                       message_drop_list=[0.2, 0.0, 0.3])
+    torch.manual_seed(1)
+    m = T.TGCN(ds, config=cfg)
+    m.train()
+    batch = T.BPR_training_data(ds, config=cfg, seed=5).all_train_data[:256]
+    res = []
+    for restricted in (False, True):
+        m.prune_forward = restricted
+        m._drop_calls = 11
+        m.zero_grad()
+        lossx = m.loss(batch)
+        sum(lossx).backward()
+        res.append(([float(v) for v in lossx], {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    m._drop_calls = 12
+    other = [float(v) for v in m.loss(batch)]
+    (l0, g0), (l1, g1) = res
+    assert other != l1                                     # another seed, another mask
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)
+    assert set(g0) == set(g1)
+    top = max(float(g.double().norm()) for g in g0.values())
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 2e-6 * top, k
+
+
 def test_compact_pull_backward_with_a_popular_neighbour():
     """The on-the-spot inverted table of the compact attention backward when one destination row collects more than
     1024 (node, slot) pairs (a long row of the SpMM kernel) and pads are present: dQ / dEj equal the scatter form's."""

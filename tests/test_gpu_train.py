@@ -286,6 +286,62 @@ def test_ngcf_message_dropout_keeps_the_fused_kernels_and_matches_masked_operato
     assert float(sum(m.loss(b))) != float(sum(l1))
 
 
+def test_ngcf_dropout_loss_path_with_repeated_batch_nodes_matches_masked_operator_form():
+    """The loss path with message dropout runs the top layer on the batch rows alone (ngcf.propagate_forward, "rows" form).
+    A batch that names a node several times (popular positive items do) must give every slot of that node the node's ONE
+    mask -- the reference drops the full [N, d] layer output (ngcf.py:85) -- so that the forward value and the gradient
+    (sent through the node's first slot) belong to the same realisation.  Loss, table gradient and W / b gradients against
+    the same pass assembled from unfused operators on ALL rows with the full-table mask; the forward is run-to-run deterministic."""
+    from tagrec_amd import ngcf as NG
+    ds = T.synth.make_cf_dataset(3000, 2500, 60000, seed=5)
+    p = [0.2, 0.0, 0.4]
+    cfg = T.get_config("ngcf", use_tag=False, dim_layer_list=[64, 64, 32], dim_latent=64, device=DEV, message_drop_list=p,
+                       reg=1e-3)
+    torch.manual_seed(1)
+    m = T.NGCF(ds, config=cfg)
+    m.train()
+    b = torch.from_numpy(T.synth.sample_bpr_epoch(ds, 0)[:64].copy())
+    b[8:24, 0] = b[0, 0]            # one user 17 times, one positive item 12 times, one negative 9 times (and as a positive)
+    b[30:41, 1] = b[3, 1]
+    b[44:52, 2] = b[3, 1]
+    b = b.to(DEV)
+    assert 3 * b.shape[0] * 16 <= m.table.shape[0]          # the compact top layer is taken
+
+    def run(calls):
+        m._drop_calls = calls
+        m.zero_grad()
+        l = m.loss(b)
+        sum(l).backward()
+        return [float(x) for x in l], {k: v.grad.clone() for k, v in m.named_parameters()}
+
+    l1, g1 = run(6)
+    l2, g2 = run(6)
+    assert l1 == l2, "same seed, same batch: the forward pass is deterministic (every slot of a node carries one mask)"
+    for k in g1:        # (the BPR backward adds repeated rows with float atomics: last-bit differences between runs)
+        np.testing.assert_allclose(g2[k].cpu().numpy(), g1[k].cpu().numpy(), rtol=1e-4, atol=1e-6 * float(g1[k].abs().max()))
+    seed = (int(m.drop_seed) << 24) + m._drop_calls
+    m.zero_grad()
+    x = m.table
+    outs = [x]
+    for k in range(3):
+        nei = H.split_mm(m.norm_adj, x)
+        s_ = torch.nn.functional.leaky_relu(torch.matmul(nei + x, m.mat[f"W1_{k}"] + m.mat[f"b1_{k}"]), 0.2)
+        b_ = torch.nn.functional.leaky_relu(torch.matmul(nei * x, m.mat[f"W2_{k}"] + m.mat[f"b2_{k}"]), 0.2)
+        x = s_ + b_
+        if p[k] > 0:
+            x = x * H.message_drop(torch.ones_like(x), p[k], NG._layer_seed(seed, k))
+        outs.append(H.normalize_rows(x))
+    ref = torch.cat(outs, dim=1)
+    nu = ds.num["user"]
+    U, I = ref[:nu], ref[nu:]
+    loss, reg = H.triplet_loss(U, I, U, I, b, cfg["mul_loss_func"])
+    (loss + cfg["reg"] * reg).backward()
+    np.testing.assert_allclose(l1, [float(loss), float(cfg["reg"] * reg)], rtol=2e-5)
+    scale = max(float(v.grad.abs().max()) for v in m.parameters())
+    for k, v in m.named_parameters():
+        np.testing.assert_allclose(g1[k].cpu().numpy(), v.grad.cpu().numpy(), rtol=2e-3, atol=2e-5 * scale, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["lightgcn", "ngcf"])
 def test_graphed_compact_restricted_step_matches_eager(name):
     """The COMPACT restricted step (layers only on the rows the batch's loss depends on: row-masked kernels, spmm_listed,
@@ -383,3 +439,40 @@ def test_adam_fused_into_the_last_backward_hop_is_bit_identical(name):
         assert not f0 and f1 == (name == "ngcf" or reg == 0.0)
         assert l0 == l1
         assert all(torch.equal(a, b) for a, b in zip(p0, p1)) and all(torch.equal(a, b) for a, b in zip(s0, s1))
+
+
+def test_fused_adam_ownership_and_commit():
+    """`Adam.fuse_into` hygiene: (1) a second optimizer built over the same model revokes the first one's fusion -- the step
+    then hands a gradient to the NEW optimizer instead of updating through the stale one's lr and state; (2) `fuse_into`
+    refuses a model whose table it does not own; (3) a second fused backward() before step() raises, and the mark is set by
+    `fused_commit` (after the launch), not by `fused_state`."""
+    ds = T.synth.make_bipartite_device(6000, 5000, 200_000, seed=11, device=DEV)
+    cfg = T.get_config("lightgcn", use_tag=False, dim_layer_list=[32, 32], dim_latent=32, device=DEV, train_batch=64)
+    torch.manual_seed(3)
+    m = T.LightGCN(ds, config=cfg)
+    m.train()
+    b = T.BPR_training_data(ds, config=cfg, seed=9).all_train_data[:64]
+    old = T.Adam(m.parameters(), lr=0.5).fuse_into(m)
+    sum(m.loss(b)).backward()
+    assert m.table.grad is None                       # fused: no gradient tensor
+    with pytest.raises(T._lib.TagrecError, match="second backward"):
+        sum(m.loss(b)).backward()
+    old.step()
+    before = m.table.detach().clone()
+    new = T.Adam(m.parameters(), lr=0.01)             # new run, same model: the old fusion must be gone
+    lossx = m.loss(b)
+    new.zero_grad()
+    sum(lossx).backward()
+    assert m.table.grad is not None and torch.equal(m.table.detach(), before)
+    new.step()
+    assert float((m.table.detach() - before).abs().max()) <= 0.0100001        # moved with the NEW lr (Adam: |step| <= lr)
+    other = T.LightGCN(ds, config=cfg)
+    with pytest.raises(T._lib.TagrecError, match="not one of this optimizer"):
+        new.fuse_into(other)
+    # fused_state alone leaves no mark
+    new.fuse_into(m)
+    new.fused_state(m.table)
+    new.fused_state(m.table)
+    new.fused_commit(m.table)
+    with pytest.raises(T._lib.TagrecError, match="second backward"):
+        new.fused_state(m.table)
