@@ -396,6 +396,37 @@ int tagrec_tgcn_attn_bwd_f32(const float* P, const float* Q, const float* WT, co
                              int64_t n, int k, int D, int A, int n_wt, float* dP, float* dQ, float* dEj,
                              float* dh, float* dWT, float* dv, float* workspace, int64_t workspace_floats, void* stream);
 
+/*   bwd, pull form without the dh round trip (three launches per relation over the relation's table inverted by
+ *   destination: graph handle `inv` with rows = destinations, colidx = source rows, vals = attention weights):
+ *     tagrec_attn_pull_da_f32 : dEj[j] = sum_p attn[p] dOut[p / k] (+ B[j]) and, on the way, da[p] = dOut[p / k] . Ej[j]
+ *                               for every listed pair (the wave that walks row j holds both operands);
+ *     tagrec_tgcn_attn_bwd_ds_f32 : from da: dP, dWT, dv as in attn_bwd, and comp [n k, 2] = (ds, relu bits of the A
+ *                               pre-activations as an int32) per pair -- 8 bytes instead of dh's 4 A; no D-wide row is read;
+ *                               w_major: a hint, the most frequent value of widx (its dWT row is summed in registers instead
+ *                               of LDS atomics; any value, or -1, gives the same result);
+ *     tagrec_attn_pull_dq_f32 : dQ[j] = v (.) sum_p ds[p] bits[p] (+ B[j]), over a handle whose colidx = PAIR ids.
+ *   tagrec_attn_keys_i32: key[i] = idx[i] - 1, pads -> n_dst: the sort keys of the inversion.  A in {16, 32} (pull_dq). */
+int tagrec_attn_pull_da_f32(const tagrec_graph* inv, const int32_t* pair, const float* dOut, const float* Ej,
+                            const float* B, float* dEj, float* da, int D, void* stream);
+/*   tagrec_attn_invert_fill: from the sort's permutation (int64 pair ids in destination order): pair (int32), src = pair / k,
+ *   val = attn[pair] -- the colidx / vals of the inverted table that attn_pull_da walks (`inv`: rows = destinations,
+ *   colidx = src, vals = val; `pair` rides along for the da store). */
+int tagrec_attn_invert_fill(const int64_t* order, const float* attn, int k, int64_t n, int32_t* pair, int32_t* src, float* val,
+                            void* stream);
+int tagrec_tgcn_attn_bwd_ds_f32(const float* P, const float* Q, const float* WT, const float* v, const int32_t* idx,
+                                const int32_t* widx, const float* attn, const float* da, int64_t n, int k, int A,
+                                int n_wt, int w_major, float* dP, float* comp, float* dWT, float* dv, float* workspace,
+                                int64_t workspace_floats, void* stream);
+int tagrec_attn_pull_dq_f32(const tagrec_graph* inv, const float* comp, const float* v, int A, const float* B, float* dQ,
+                            void* stream);
+int tagrec_attn_keys_i32(const int32_t* idx, int64_t n, int32_t n_dst, int32_t* key, void* stream);
+/*     tagrec_attn_seg_dq_f32 : the same dQ from the pair list SORTED by destination (dest_sorted = the sorted keys, entries
+ *                               with dest >= n_dst are the pads at the tail), as a balanced segmented sum: 256 entries per
+ *                               wavefront, a finished segment ADDED to dQ by float atomics (the caller zeroes dQ; two relations
+ *                               of one neighbour type add into the same buffer).  A in {4, 8, 16, 32}. */
+int tagrec_attn_seg_dq_f32(const int32_t* dest_sorted, const int32_t* pair_sorted, int64_t n_entries, int32_t n_dst,
+                           const float* comp, const float* v, int A, float* dQ, void* stream);
+
 /* ---- TGCN type-level attention + bit/vector convolutions + fusion layer, fused (tgcn.py:78-106) ------------
  * One node type per call.  T0/T1/T2 [n, D]: the (user-side, item-side, tag-side) vectors of each node, in
  * that order.  U [D, A], q [A], p [A]; wb [C, 3] (Conv2d(1,C,(3,1)) weight); w1 [V, D], w2 [V, 2, D],
@@ -432,6 +463,29 @@ int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, c
                             const float* wb, const float* out, const float* dOut, const float* dfeat, const float* dS,
                             int64_t n, int D, int Dout, int C, int V, float* result, float* workspace,
                             int64_t workspace_floats, void* stream);
+
+/* ---- tall-skinny dense products of the TGCN step (tgcn.py:20-37 after the split of the attention's matmuls) ----
+ * exact-fp32 MFMA, HBM-bound: a node table times a small matrix, and the reverse products.  K, NO in {16, 32, 64, 128}.
+ *   tall_mm : Y[n, NO] (+)= [X1 | X2][sel][n, K] W[K, NO] + bias.
+ *             X2 != NULL: the tall operand is two tensors of K/2 columns each; sel (int64 [n], may be NULL) gathers its rows.
+ *             W(k, c) = W1[k * w_sk + c * w_sc] (strides in floats: a transposed matrix is a stride pair); w_split = 1: W2
+ *             holds the rows k >= K/2, w_split = 2: W2 holds the columns c >= NO/2 (same strides).
+ *             Y2 != NULL: columns [NO/2, NO) go to Y2, both outputs with row stride NO/2 (b1 / b2: their biases, may be NULL).
+ *             accumulate != 0: the product is added to what Y holds.
+ *   tall_wgrad : dW[KI, NO] (+)= X^T [dY1 | dY2] and db1 / db2 (+)= column sums of dY1 / dY2 (any output may be NULL),
+ *             contraction over the n rows; per-wave partials in `workspace` (tagrec_tall_wgrad_workspace(KI, NO) floats) folded
+ *             in a fixed order.
+ *   small_mm : C[M, N] (+)= A B with A(i, k) = A[i * sam + k * sak], B(k, j) = B[k * sbk + j * sbn] (look-up-table sized).
+ *   row_add_at : dst[pos[i], :] += src[i, :] for DISTINCT positions (plain read-modify-write). */
+int tagrec_tall_mm_f32(const float* X1, const float* X2, const int64_t* sel, int64_t n, int K, int NO, const float* W1,
+                       const float* W2, int64_t w_sk, int64_t w_sc, int w_split, const float* b1, const float* b2,
+                       float* Y1, float* Y2, int accumulate, void* stream);
+int64_t tagrec_tall_wgrad_workspace(int KI, int NO);
+int tagrec_tall_wgrad_f32(const float* X, const float* dY1, const float* dY2, int64_t n, int KI, int NO, float* dW,
+                          float* db1, float* db2, int acc_w, int acc_b, float* workspace, int64_t workspace_floats, void* stream);
+int tagrec_small_mm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak,
+                        int64_t sbk, int64_t sbn, int accumulate, void* stream);
+int tagrec_row_add_at_f32(float* dst, const int64_t* pos, const float* src, int64_t n_rows, int D, void* stream);
 
 /* ---- bandwidth probes (measured ceilings of the box next to the 8 TB/s specification) ----------------
  * a = b + s * c over n floats (stream triad; 12 bytes per element), and a random whole-row gather with the access shape

@@ -71,6 +71,12 @@ _SIGNATURES = {
     "tagrec_tgcn_attn_workspace": [c_int, c_int],
     "tagrec_tgcn_attn_fwd_f32": [c_void_p] * 7 + [c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tagrec_tgcn_attn_bwd_f32": [c_void_p] * 9 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [c_int64, c_void_p],
+    "tagrec_attn_pull_da_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_attn_invert_fill": [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tagrec_tgcn_attn_bwd_ds_f32": [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_int64, c_void_p],
+    "tagrec_attn_pull_dq_f32": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "tagrec_attn_seg_dq_f32": [c_void_p, c_void_p, c_int64, ctypes.c_int32, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "tagrec_attn_keys_i32": [c_void_p, c_int64, ctypes.c_int32, c_void_p, c_void_p],
     "tagrec_tgcn_fuse_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 12,
     "tagrec_tgcn_fuse_bwd_workspace": [c_int],
     "tagrec_tgcn_fuse_bwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 18
@@ -124,6 +130,13 @@ _SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p],
     "tagrec_spmm_axpy_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_float, c_float, c_float, c_float, c_int64, c_int, c_void_p],
+    "tagrec_tall_mm_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
+                           c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_tall_wgrad_workspace": [c_int, c_int],
+    "tagrec_tall_wgrad_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                              c_void_p, c_int64, c_void_p],
+    "tagrec_small_mm_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p],
+    "tagrec_row_add_at_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "tagrec_probe_triad_f32": [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p],
     "tagrec_probe_gather_out_floats": [],
     "tagrec_probe_gather_rows_f32": [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p],

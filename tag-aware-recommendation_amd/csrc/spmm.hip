@@ -485,6 +485,173 @@ __global__ __launch_bounds__(256) void mark_rows_kernel(GraphView g, const int64
   for (int64_t j = b0 + threadIdx.x; j < b1; j += blockDim.x) flags[g.col[j]] = 1;
 }
 
+// ---- TGCN attention backward over an inverted neighbour table (csrc/tgcn.hip, model/tgcn.py:20-37) ------------------------
+// Row j of the table lists the (source node v, slot n) pairs that point at destination j, as pair ids p = v k + n in
+// `g.col` (g.val is not read).  Two pulls walk it, both on the long-row machinery above (chunks first, fixed-order fold):
+//
+//   (attn_pull_da reads the pair's source row from g.col and its attention weight from g.val, and the pair id from a
+//   parallel array; attn_pull_dq reads pair ids from g.col)
+//   attn_pull_da : dEj[j] = sum_p attn[p] dOut[p / k]  (+ B[j])  -- and, since the wave that walks row j holds BOTH
+//                  operands of it, da[p] = dOut[p / k] . Ej[j]: the softmax-backward input of pair p.  The source-centric
+//                  backward kernel then does not gather the D-wide neighbour rows a second time (512 of its 776 bytes per
+//                  pair at D = 128).
+//   attn_pull_dq : dQ[j] = v (.) sum_p ds[p] mask[p]  (+ B[j]) from the COMPRESSED pre-activation gradients: per pair one
+//                  float ds and the A relu bits, 8 bytes instead of the 4 A bytes of dh.
+// sum over the LPR lanes of a lane group with DPP inside a 16-lane row (register speed: no LDS round trip), bpermutes across rows
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int LPR>
+__device__ __forceinline__ float group_sum_dpp(float v) {
+  if constexpr (LPR >= 2) v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+  if constexpr (LPR >= 4) v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) v = dpp_add<0x141>(v);     // row_half_mirror
+  if constexpr (LPR >= 16) v = dpp_add<0x140>(v);    // row_mirror
+  if constexpr (LPR >= 32) v += __shfl_xor(v, 16);
+  if constexpr (LPR >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 gather_pairs_da(const GraphView& g, const int32_t* __restrict__ pair, int64_t start, int64_t end,
+                                                  int lane, const float* __restrict__ dOut, const float4 own,
+                                                  float* __restrict__ da) {
+  constexpr int NPI = kWave / LPR;
+  const int q = lane / LPR, c = lane % LPR;
+  const float4* __restrict__ Xv = reinterpret_cast<const float4*>(dOut) + c;
+  float4 acc = f4_zero();
+  for (int64_t base = start; base < end; base += kWave) {
+    const int n = (end - base) < kWave ? static_cast<int>(end - base) : kWave;
+    int my_src = 0, my_pair = 0;
+    float my_val = 0.f, my_da = 0.f;
+    if (lane < n) {                      // source row and attention weight of the pair, streamed (filled by attn_invert_fill)
+      my_src = ld_stream(g.col + base + lane);
+      my_val = ld_stream(g.val + base + lane);
+      my_pair = ld_stream(pair + base + lane);
+    }
+    const int groups = (n + NPI - 1) / NPI;
+    for (int gi = 0; gi < groups; gi += 4) {
+      float4 x[4];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = (gi + u) * NPI + q;
+        const int src = __shfl(my_src, j & (kWave - 1));
+        const float w = __shfl(my_val, j & (kWave - 1));
+        const bool ok = j < n;
+        v[u] = ok ? w : 0.f;
+        x[u] = ok ? Xv[static_cast<int64_t>(src) * LPR] : f4_zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f4_fma(acc, v[u], x[u]);
+        const float d = group_sum_dpp<LPR>(f4_dot(x[u], own));
+        // entry (gi + u) NPI + q' sits in lane group q': lane L of the batch collects its own entry's dot product, so that the
+        // 64 results leave with ONE store instruction (two active lanes per store cost a third of the kernel)
+        const float dd = __shfl(d, (lane % NPI) * LPR);
+        if (lane / NPI == gi + u) my_da = dd;
+      }
+    }
+    if (lane < n) da[my_pair] = my_da;
+  }
+#pragma unroll
+  for (int m = LPR; m < kWave; m <<= 1) {
+    const float4 o = f4_shfl_xor(acc, m);
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+  }
+  return acc;
+}
+
+template <int LPR, int EPI>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void attn_pull_da_kernel(GraphView g, const int32_t* __restrict__ pair,
+                                                                               const float* __restrict__ dOut,
+                                                                               const float* __restrict__ Ej, float* __restrict__ da,
+                                                                               EpiArgs e, LongView lv) {
+  const int lane = threadIdx.x & (kWave - 1);
+  int64_t r, start, end;
+  int64_t chunk = -1;
+  if (blockIdx.x < lv.chunk_blocks) {
+    chunk = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (chunk >= lv.n_chunks) return;
+    const int2 d = lv.chunk_desc[chunk];
+    r = lv.long_rows[d.x];
+    start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
+    const int64_t row_end = g.rowptr[r + 1];
+    end = (start + kChunk < row_end) ? start + kChunk : row_end;
+  } else {
+    r = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= g.n_rows) return;
+    start = g.rowptr[r];
+    end = g.rowptr[r + 1];
+    if (end - start > kLongRow) return;
+  }
+  const float4 own = start < end ? reinterpret_cast<const float4*>(Ej)[r * LPR + (lane % LPR)] : f4_zero();
+  const float4 acc = gather_pairs_da<LPR>(g, pair, start, end, lane, dOut, own, da);
+  if (chunk >= 0) {
+    if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[chunk * LPR + lane] = acc;
+    return;
+  }
+  row_epilogue<LPR, EPI>(acc, r, lane, e);
+}
+
+// A lanes per pair, 64 / A pairs per step; on return lanes [0, A/4) hold the row's float4 columns of v (.) sum
+template <int A>
+__device__ __forceinline__ float4 gather_pairs_dq(const int32_t* __restrict__ pair, int64_t start, int64_t end, int lane,
+                                                  const float2* __restrict__ comp, const float* __restrict__ vv) {
+  constexpr int SLOTS = kWave / A;
+  const int slot = lane / A, c = lane % A;
+  float acc = 0.f;
+  for (int64_t base = start; base < end; base += kWave) {
+    const int n = (end - base) < kWave ? static_cast<int>(end - base) : kWave;
+    float my_ds = 0.f;
+    int my_bits = 0;
+    if (lane < n) {
+      const float2 cv = comp[ld_stream(pair + base + lane)];
+      my_ds = cv.x;
+      my_bits = __float_as_int(cv.y);
+    }
+    const int steps = (n + SLOTS - 1) / SLOTS;
+    for (int i = 0; i < steps; ++i) {
+      const int j = i * SLOTS + slot;                 // (lanes past n hold ds = 0)
+      const float ds = __shfl(my_ds, j & (kWave - 1));
+      const int bits = __shfl(my_bits, j & (kWave - 1));
+      acc += ((bits >> c) & 1) ? ds : 0.f;
+    }
+  }
+#pragma unroll
+  for (int m = A; m < kWave; m <<= 1) acc += __shfl_xor(acc, m);
+  acc *= vv[c];
+  // scalar-per-lane -> float4 columns on the first A/4 lanes
+  const int b = (lane * 4) & (kWave - 1);
+  return make_float4(__shfl(acc, b), __shfl(acc, b + 1), __shfl(acc, b + 2), __shfl(acc, b + 3));
+}
+
+template <int A, int EPI>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void attn_pull_dq_kernel(GraphView g, const float2* __restrict__ comp,
+                                                                               const float* __restrict__ vv, EpiArgs e, LongView lv) {
+  constexpr int LPR = A / 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  if (blockIdx.x < lv.chunk_blocks) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (c >= lv.n_chunks) return;
+    const int2 d = lv.chunk_desc[c];
+    const int64_t r = lv.long_rows[d.x];
+    const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
+    const int64_t row_end = g.rowptr[r + 1];
+    const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
+    const float4 acc = gather_pairs_dq<A>(g.col, start, end, lane, comp, vv);
+    if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[c * LPR + lane] = acc;
+    return;
+  }
+  const int64_t r = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (r >= g.n_rows) return;
+  const int64_t start = g.rowptr[r], end = g.rowptr[r + 1];
+  if (end - start > kLongRow) return;
+  const float4 acc = gather_pairs_dq<A>(g.col, start, end, lane, comp, vv);
+  row_epilogue<LPR, EPI>(acc, r, lane, e);
+}
+
 // ---- row-length scan at graph creation ---------------------------------------------------------
 __global__ void count_long_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, unsigned long long* counters) {
   const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1018,4 +1185,93 @@ extern "C" int tagrec_spmm_ss_rows_f32(const tagrec_graph* g, const float* X, fl
   TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_ss_rows: D must be 8 .. 256, a power of two");
   EpiArgs e{Y, ss, nullptr, nullptr, nullptr, nullptr, 0.f, DropMask{0.f, 0}, nullptr, nullptr, nullptr, row_mask};
   return launch_spmm<EPI_SS>(g, X, e, D, stream, "spmm_ss_rows");
+}
+
+// ---- TGCN attention backward pulls (see attn_pull_da_kernel / attn_pull_dq_kernel) ------------------------------------
+namespace {
+template <int LPR, int EPI>
+int launch_pull_da(const tagrec_graph* g, const int32_t* pair, const float* dOut, const float* Ej, float* da, const EpiArgs& e,
+                   hipStream_t s) {
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
+  const int threads = kWavesPerBlock * kWave;
+  const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  LongView lv{g->long_rows, g->chunk_desc, g->n_chunks, nullptr, 0};
+  if (g->n_long > 0) {
+    int rc = ensure_slab(g, LPR * 4);
+    if (rc != TAGREC_OK) return rc;
+    lv.slab = g->slab;
+    lv.chunk_blocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+  }
+  attn_pull_da_kernel<LPR, EPI><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, pair, dOut, Ej, da, e, lv);
+  TAGREC_LAUNCH_CHECK();
+  if (g->n_long > 0) {
+    const unsigned fblocks = static_cast<unsigned>((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+    spmm_finish_kernel<LPR, EPI><<<fblocks, threads, 0, s>>>(gv, g->long_rows, g->long_base, g->n_long, g->slab, e);
+    TAGREC_LAUNCH_CHECK();
+  }
+  return TAGREC_OK;
+}
+
+template <int A, int EPI>
+int launch_pull_dq(const tagrec_graph* g, const float2* comp, const float* vv, const EpiArgs& e, hipStream_t s) {
+  constexpr int LPR = A / 4;
+  const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
+  const int threads = kWavesPerBlock * kWave;
+  const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  LongView lv{g->long_rows, g->chunk_desc, g->n_chunks, nullptr, 0};
+  if (g->n_long > 0) {
+    int rc = ensure_slab(g, A);
+    if (rc != TAGREC_OK) return rc;
+    lv.slab = g->slab;
+    lv.chunk_blocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+  }
+  attn_pull_dq_kernel<A, EPI><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, comp, vv, e, lv);
+  TAGREC_LAUNCH_CHECK();
+  if (g->n_long > 0) {
+    const unsigned fblocks = static_cast<unsigned>((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock);
+    spmm_finish_kernel<LPR, EPI><<<fblocks, threads, 0, s>>>(gv, g->long_rows, g->long_base, g->n_long, g->slab, e);
+    TAGREC_LAUNCH_CHECK();
+  }
+  return TAGREC_OK;
+}
+}  // namespace
+
+extern "C" int tagrec_attn_pull_da_f32(const tagrec_graph* g, const int32_t* pair, const float* dOut, const float* Ej,
+                                       const float* B, float* dEj, float* da, int D, void* stream) {
+  TAGREC_REQUIRE(g != nullptr, "attn_pull_da: null graph handle");
+  if (g->n_rows == 0) return TAGREC_OK;
+  TAGREC_REQUIRE(Ej && dEj && (g->nnz == 0 || (dOut && pair && da)), "attn_pull_da: null pointer");
+  TAGREC_REQUIRE(aligned16(dOut) && aligned16(Ej) && aligned16(dEj) && (!B || aligned16(B)), "attn_pull_da: rows must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  EpiArgs e{dEj, nullptr, nullptr, nullptr, B, nullptr, 1.0f, DropMask{0.f, 0}, nullptr, nullptr, nullptr, nullptr, nullptr};
+#define PULL(L) (B ? launch_pull_da<L, EPI_AXPY>(g, pair, dOut, Ej, da, e, s) : launch_pull_da<L, EPI_NONE>(g, pair, dOut, Ej, da, e, s))
+  switch (D) {
+    case 16: return PULL(4);
+    case 32: return PULL(8);
+    case 64: return PULL(16);
+    case 128: return PULL(32);
+    case 256: return PULL(64);
+    default: break;
+  }
+#undef PULL
+  return fail(TAGREC_E_UNSUPPORTED, "attn_pull_da: D must be 16, 32, 64, 128 or 256");
+}
+
+extern "C" int tagrec_attn_pull_dq_f32(const tagrec_graph* g, const float* comp, const float* v, int A, const float* B, float* dQ,
+                                       void* stream) {
+  TAGREC_REQUIRE(g != nullptr, "attn_pull_dq: null graph handle");
+  if (g->n_rows == 0) return TAGREC_OK;
+  TAGREC_REQUIRE(v && dQ && (g->nnz == 0 || comp), "attn_pull_dq: null pointer");
+  TAGREC_REQUIRE(aligned16(dQ) && (!B || aligned16(B)) && (reinterpret_cast<uintptr_t>(comp) & 7u) == 0, "attn_pull_dq: misaligned buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  EpiArgs e{dQ, nullptr, nullptr, nullptr, B, nullptr, 1.0f, DropMask{0.f, 0}, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const float2* c2 = reinterpret_cast<const float2*>(comp);
+#define PULL(AA) (B ? launch_pull_dq<AA, EPI_AXPY>(g, c2, v, e, s) : launch_pull_dq<AA, EPI_NONE>(g, c2, v, e, s))
+  switch (A) {
+    case 16: return PULL(16);
+    case 32: return PULL(32);
+    default: break;
+  }
+#undef PULL
+  return fail(TAGREC_E_UNSUPPORTED, "attn_pull_dq: A must be 16 or 32 (the relu bits of a pair travel in one 32-bit word)");
 }

@@ -198,6 +198,179 @@ __global__ __launch_bounds__(kAttnThreads) void tgcn_attn_bwd_kernel(const float
   for (int i = threadIdx.x; i < (n_wt + 1) * A; i += kAttnThreads) o[i] = sh[i];
 }
 
+// Source-centric half of the backward pass when the D-wide work has been done by the destination-centric pull
+// (attn_pull_da_kernel, csrc/spmm.hip): da[v, n] = dOut[v] . Ej[idx_n] arrives as an input, so this kernel touches no
+// embedding row at all -- per (node, neighbour) it reads the A-wide Q row and writes EIGHT bytes: the softmax-backward
+// scalar ds and the A relu bits of the pre-activation, from which the second pull (attn_pull_dq_kernel) rebuilds
+// dh = ds v (.) [h > 0].  dP, dWT, dv as in the kernel above.  A <= 32.
+__global__ __launch_bounds__(kAttnThreads) void tgcn_attn_bwd_ds_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                                        const float* __restrict__ WT, const float* __restrict__ vv,
+                                                                        const int32_t* __restrict__ idx, const int32_t* __restrict__ widx,
+                                                                        const float* __restrict__ attn, const float* __restrict__ da,
+                                                                        int64_t n, int k, int A, int n_wt, float* __restrict__ dP,
+                                                                        float2* __restrict__ comp, float* __restrict__ part, int copies,
+                                                                        int w_major) {
+  // dWT partials in LDS, one private copy per (wave, lane group) when they fit (`copies` = 4 * 64 / A): edge weights are
+  // mostly 1, so the lane groups of a wave -- and the waves of a block -- would otherwise add into the SAME few addresses
+  // and serialise (measured: 56 % of this kernel's time with one shared copy).  Then [A] dv partial.
+  extern __shared__ float sh[];
+  const int wt_elems = n_wt * A;
+  float* sh_v = sh + copies * wt_elems;
+  for (int i = threadIdx.x; i < copies * wt_elems + A; i += kAttnThreads) sh[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1);
+  const int npi = kWave / A, grp = lane / A, c = lane % A;
+  float* sh_wt = sh + (copies > 1 ? ((threadIdx.x >> 6) * npi + grp) * wt_elems : 0);
+  const float vc = vv[c];
+  const unsigned long long gmask = A >= 32 ? 0xFFFFFFFFull : ((1ull << A) - 1ull);
+  float dv_acc = 0.f;
+  float wt_major = 0.f;        // the share of dWT[w_major]: the most frequent edge weight stays in a register for the whole launch
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kAttnWaves;
+  // the node's scalars (neighbour ids, weight ids, attention weights, da) are fetched one node ahead
+  int64_t v = static_cast<int64_t>(blockIdx.x) * kAttnWaves + (threadIdx.x >> 6);
+  int nj = 0, nw = 0;
+  float na = 0.f, nd = 0.f, npc = 0.f;
+  if (v < n) {
+    if (lane < k) { nj = idx[v * k + lane]; nw = widx[v * k + lane]; na = attn[v * k + lane]; nd = da[v * k + lane]; }
+    npc = P[v * A + c];
+  }
+  for (; v < n; v += stride) {
+    const int j = nj, w = nw;
+    const float a = na, d = (j != 0) ? nd : 0.f;   // a pad slot is a zero row: its da is 0 (the slot holds garbage)
+    const float pc = npc;
+    const int64_t vn = v + stride;
+    if (vn < n) {
+      if (lane < k) { nj = idx[vn * k + lane]; nw = widx[vn * k + lane]; na = attn[vn * k + lane]; nd = da[vn * k + lane]; }
+      npc = P[vn * A + c];
+    }
+    const float dot = wave_add(a * d);
+    const float ds = a * (d - dot);
+    float dp_acc = 0.f;
+    int my_bits = 0;                  // lane n < k collects the relu bits of neighbour n: one coalesced store at the end
+    // UB steps at a time: all their Q / WT reads are issued before the first is used (the steps of a node are otherwise a
+    // chain of dependent memory latencies, and a wave walks one node at a time)
+    constexpr int UB = 8;
+    for (int n0 = 0; n0 < k; n0 += UB * npi) {
+      float hq[UB], hw[UB], dsn[UB];
+      int wnv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int nn = n0 + u * npi + grp;
+        const int jn = __shfl(j, nn & (kWave - 1));
+        wnv[u] = __shfl(w, nn & (kWave - 1));
+        dsn[u] = __shfl(ds, nn & (kWave - 1));
+        const bool in = nn < k;
+        hw[u] = in ? WT[static_cast<int64_t>(wnv[u]) * A + c] : 0.f;
+        hq[u] = (in && jn) ? Q[static_cast<int64_t>(jn - 1) * A + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int nn = n0 + u * npi + grp;
+        if (n0 + u * npi < k) {                           // (wave-uniform)
+          const float h = pc + hw[u] + hq[u];
+          const bool pos = nn < k && h > 0.f;
+          if (pos) {
+            const float dhv = dsn[u] * vc;
+            dp_acc += dhv;
+            dv_acc = fmaf(dsn[u], h, dv_acc);
+            if (wnv[u] == w_major) wt_major += dhv;
+            else atomicAdd(&sh_wt[wnv[u] * A + c], dhv);
+          }
+          const unsigned long long m = __ballot(pos);
+          const int first = n0 + u * npi;                 // this step covers neighbours [first, first + npi)
+          if (lane >= first && lane < first + npi) my_bits = static_cast<int>((m >> ((lane - first) * A)) & gmask);
+        }
+      }
+    }
+    if (lane < k) comp[v * k + lane] = make_float2(ds, __int_as_float(my_bits));
+    for (int m = A; m < kWave; m <<= 1) dp_acc += __shfl_xor(dp_acc, m);
+    if (lane < A) dP[v * A + lane] = dp_acc;
+  }
+  for (int m = A; m < kWave; m <<= 1) dv_acc += __shfl_xor(dv_acc, m);
+  if (lane < A) atomicAdd(&sh_v[lane], dv_acc);
+  if (w_major >= 0 && w_major < n_wt) atomicAdd(&sh_wt[w_major * A + c], wt_major);
+  __syncthreads();
+  float* o = part + static_cast<int64_t>(blockIdx.x) * (n_wt + 1) * A;
+  for (int i = threadIdx.x; i < wt_elems; i += kAttnThreads) {
+    float t = 0.f;
+    for (int cp = 0; cp < copies; ++cp) t += sh[cp * wt_elems + i];          // fixed order
+    o[i] = t;
+  }
+  for (int i = threadIdx.x; i < A; i += kAttnThreads) o[wt_elems + i] = sh_v[i];
+}
+
+// dQ[j] += v (.) sum over the pairs that point at j of ds[p] bits[p], from the pair list SORTED by destination: every wave
+// takes kSegEntries consecutive entries (perfectly balanced, no row pointer, no per-row latency floor -- a destination
+// collects ~6 pairs on average and the row-per-wave pull spent its time waiting on rowptr -> pair -> comp chains), walks
+// them with the destination in a scalar register and adds a finished segment to dQ with one 4 A-byte float-atomic
+// instruction.  Destinations that straddle two waves are added twice (hence atomics; dQ is zeroed by the caller).
+constexpr int kSegEntries = 256;
+template <int A>
+__global__ __launch_bounds__(256) void attn_seg_dq_kernel(const int32_t* __restrict__ dest, const int32_t* __restrict__ pair,
+                                                           int64_t n_entries, int32_t n_dst, const float2* __restrict__ comp,
+                                                           const float* __restrict__ vv, float* __restrict__ dQ) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wv = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t e0 = wv * kSegEntries;
+  if (e0 >= n_entries) return;
+  const int64_t e1 = e0 + kSegEntries < n_entries ? e0 + kSegEntries : n_entries;
+  const int c = lane % A;
+  const bool worker = lane < A;
+  const float vc = vv[c];
+  int cur = -1;
+  float acc = 0.f;
+  bool done = false;
+  for (int64_t base = e0; base < e1 && !done; base += kWave) {
+    const int n = (e1 - base) < kWave ? static_cast<int>(e1 - base) : kWave;
+    int my_dest = n_dst;
+    float my_ds = 0.f;
+    int my_bits = 0;
+    if (lane < n) {
+      my_dest = dest[base + lane];
+      if (my_dest < n_dst) {
+        const float2 cv = comp[pair[base + lane]];
+        my_ds = cv.x;
+        my_bits = __float_as_int(cv.y);
+      }
+    }
+    for (int i = 0; i < n; ++i) {
+      const int d = __builtin_amdgcn_readlane(my_dest, i);
+      if (d >= n_dst) { done = true; break; }            // pads sort behind the last destination: nothing follows
+      if (d != cur) {
+        if (cur >= 0 && worker) atomicAdd(&dQ[static_cast<int64_t>(cur) * A + c], acc * vc);
+        acc = 0.f;
+        cur = d;
+      }
+      const float ds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_ds), i));
+      const int bits = __builtin_amdgcn_readlane(my_bits, i);
+      acc += ((bits >> c) & 1) ? ds : 0.f;
+    }
+  }
+  if (cur >= 0 && worker) atomicAdd(&dQ[static_cast<int64_t>(cur) * A + c], acc * vc);
+}
+
+// after the sort: pair id (as int32), source row and attention weight of every sorted entry, in one streaming pass
+__global__ __launch_bounds__(256) void attn_invert_fill_kernel(const int64_t* __restrict__ order, const float* __restrict__ attn, int k,
+                                                                int64_t n, int32_t* __restrict__ pair, int32_t* __restrict__ src,
+                                                                float* __restrict__ val) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+    const int64_t p = order[i];
+    pair[i] = static_cast<int32_t>(p);
+    src[i] = static_cast<int32_t>(p / k);
+    val[i] = attn[p];
+  }
+}
+
+// sort keys of an on-the-spot table inversion: destination row of every (node, slot) pair, pads behind the last row
+__global__ __launch_bounds__(256) void attn_keys_kernel(const int32_t* __restrict__ idx, int64_t n, int32_t n_dst, int32_t* __restrict__ key) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+    const int32_t j = idx[i];
+    key[i] = j > 0 ? j - 1 : n_dst;
+  }
+}
+
 // fold the per-block partial tables: 16 threads per element take every 16th block, then a fixed-order combine
 // (deterministic given the partials; a single thread per element would walk up to 2048 dependent loads)
 __global__ __launch_bounds__(256) void tgcn_attn_fold_kernel(const float* __restrict__ part, int n_blocks, int elems, int split,
@@ -295,6 +468,73 @@ extern "C" int tagrec_tgcn_attn_bwd_f32(const float* P, const float* Q, const fl
 #undef LAUNCH
   TAGREC_LAUNCH_CHECK();
   tgcn_attn_fold_kernel<<<(elems + 15) / 16, 256, 0, s>>>(workspace, static_cast<int>(blocks), elems, n_wt * A, dWT, dv);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_tgcn_attn_bwd_ds_f32(const float* P, const float* Q, const float* WT, const float* v, const int32_t* idx,
+                                           const int32_t* widx, const float* attn, const float* da, int64_t n, int k, int A,
+                                           int n_wt, int w_major, float* dP, float* comp, float* dWT, float* dv, float* workspace,
+                                           int64_t workspace_floats, void* stream) {
+  TAGREC_REQUIRE(P && Q && WT && v && idx && widx && attn && da && dP && comp && dWT && dv && workspace, "tgcn_attn_bwd_ds: null pointer");
+  TAGREC_REQUIRE((A == 4 || A == 8 || A == 16 || A == 32) && k >= 1 && k <= kWave, "tgcn_attn_bwd_ds: need A in {4,8,16,32}, 1 <= k <= 64");
+  TAGREC_REQUIRE(n_wt >= 1 && static_cast<size_t>(n_wt + 1) * A * sizeof(float) <= 48 * 1024, "tgcn_attn_bwd_ds: weight table too large for LDS");
+  TAGREC_REQUIRE(workspace_floats >= tagrec_tgcn_attn_workspace(n_wt, A), "tgcn_attn_bwd_ds: workspace too small");
+  TAGREC_REQUIRE((reinterpret_cast<uintptr_t>(comp) & 7u) == 0, "tgcn_attn_bwd_ds: comp must be 8-byte aligned");
+  if (n <= 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int elems = (n_wt + 1) * A;
+  int copies = kAttnWaves * (kWave / A);                        // one dWT partial per (wave, lane group) while that fits
+  if (static_cast<size_t>(copies) * n_wt * A * sizeof(float) > 40 * 1024) copies = 1;
+  const size_t lds = (static_cast<size_t>(copies) * n_wt * A + A) * sizeof(float);
+  const int64_t want = (n + kAttnWaves - 1) / kAttnWaves;
+  const unsigned blocks = static_cast<unsigned>(want < kAttnBlocks ? want : kAttnBlocks);
+  tgcn_attn_bwd_ds_kernel<<<blocks, kAttnThreads, lds, s>>>(P, Q, WT, v, idx, widx, attn, da, n, k, A, n_wt, dP,
+                                                             reinterpret_cast<float2*>(comp), workspace, copies, w_major);
+  TAGREC_LAUNCH_CHECK();
+  tgcn_attn_fold_kernel<<<(elems + 15) / 16, 256, 0, s>>>(workspace, static_cast<int>(blocks), elems, n_wt * A, dWT, dv);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_attn_keys_i32(const int32_t* idx, int64_t n, int32_t n_dst, int32_t* key, void* stream) {
+  TAGREC_REQUIRE(n >= 0 && (n == 0 || (idx && key)), "attn_keys: null pointer");
+  if (n == 0) return TAGREC_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  attn_keys_kernel<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(idx, n, n_dst, key);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_attn_seg_dq_f32(const int32_t* dest_sorted, const int32_t* pair_sorted, int64_t n_entries, int32_t n_dst,
+                                      const float* comp, const float* v, int A, float* dQ, void* stream) {
+  TAGREC_REQUIRE(n_entries >= 0 && n_dst >= 0, "attn_seg_dq: bad size");
+  if (n_entries == 0) return TAGREC_OK;
+  TAGREC_REQUIRE(dest_sorted && pair_sorted && comp && v && dQ, "attn_seg_dq: null pointer");
+  TAGREC_REQUIRE((reinterpret_cast<uintptr_t>(comp) & 7u) == 0, "attn_seg_dq: comp must be 8-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t waves = (n_entries + kSegEntries - 1) / kSegEntries;
+  const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
+  const float2* c2 = reinterpret_cast<const float2*>(comp);
+  switch (A) {
+    case 4: attn_seg_dq_kernel<4><<<blocks, 256, 0, s>>>(dest_sorted, pair_sorted, n_entries, n_dst, c2, v, dQ); break;
+    case 8: attn_seg_dq_kernel<8><<<blocks, 256, 0, s>>>(dest_sorted, pair_sorted, n_entries, n_dst, c2, v, dQ); break;
+    case 16: attn_seg_dq_kernel<16><<<blocks, 256, 0, s>>>(dest_sorted, pair_sorted, n_entries, n_dst, c2, v, dQ); break;
+    case 32: attn_seg_dq_kernel<32><<<blocks, 256, 0, s>>>(dest_sorted, pair_sorted, n_entries, n_dst, c2, v, dQ); break;
+    default: return fail(TAGREC_E_UNSUPPORTED, "attn_seg_dq: A must be 4, 8, 16 or 32");
+  }
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_attn_invert_fill(const int64_t* order, const float* attn, int k, int64_t n, int32_t* pair, int32_t* src,
+                                       float* val, void* stream) {
+  TAGREC_REQUIRE(n >= 0 && k >= 1 && (n == 0 || (order && attn && pair && src && val)), "attn_invert_fill: null pointer");
+  if (n == 0) return TAGREC_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  attn_invert_fill_kernel<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(order, attn, k, n, pair, src, val);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

@@ -623,6 +623,8 @@ class TGCN(nn.Module):
                 return t[:, :self.neighbor_k].to(self.device, torch.int32).contiguous()
             return torch.as_tensor(np.asarray(t)[:, :self.neighbor_k].astype(np.int32)).contiguous().to(self.device)
         self.nbr = [tuple(up(t) for t in pair) for pair in neighbors]
+        # most frequent weight index per relation (a hint for the attention backward: that row of dWT is summed in registers)
+        self.w_major = [int(torch.bincount(w.flatten()[:2_000_000].long()).argmax()) if w.numel() else -1 for _, w in self.nbr]
         n_dst = [self.num_item, self.num_tag, self.num_user, self.num_tag, self.num_user, self.num_item]
         self.inv = [InverseTable(self.nbr[r][0], n_dst[r]) for r in range(6)] if self.pull_backward else None
         self._eval_cache = None

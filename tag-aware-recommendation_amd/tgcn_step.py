@@ -22,7 +22,7 @@ Same loss and gradients as the all-rows pass (`TGCN.forward()` + triplet loss + 
 """
 import torch
 
-from . import _lib, help as H
+from . import _lib, help as H, proj as PJ
 
 TYPES = ("user", "item", "tag")
 RELATIONS = (("user", "item"), ("user", "tag"), ("item", "user"), ("item", "tag"), ("tag", "user"), ("tag", "item"))
@@ -43,6 +43,7 @@ def layer_params(layer):
 
 
 N_LAYER_PARAMS = 21
+SEGMENTED_DQ = True      # dQ of the pull-form attention backward: segmented sum over the sorted pairs (False: row-per-wave pull)
 
 
 def _drop_seed(seed, layer, t):
@@ -50,12 +51,13 @@ def _drop_seed(seed, layer, t):
 
 
 # ------------------------------------------------------------------------------------------------ raw kernel calls
-def attn_fwd(P, Q, WT, v, Ej, idx, widx):
+def attn_fwd(P, Q, WT, v, Ej, idx, widx, out=None):
     from . import tgcn as TG
     n, A = P.shape
     k, D = idx.shape[1], Ej.shape[1]
     attn = torch.empty(n, k, dtype=torch.float32, device=P.device)
-    out = torch.empty(n, D, dtype=torch.float32, device=P.device)
+    if out is None:
+        out = torch.empty(n, D, dtype=torch.float32, device=P.device)
     _lib.check(TG._timed("attn_fwd", _lib.load().tagrec_tgcn_attn_fwd_f32, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v),
                          _lib.ptr(Ej), _lib.ptr(idx), _lib.ptr(widx), n, k, D, A, _lib.ptr(attn), _lib.ptr(out),
                          _lib.stream_ptr()), "tgcn_attn_fwd")
@@ -77,6 +79,52 @@ def attn_bwd(P, Q, WT, v, Ej, idx, widx, attn, d_out, dQ, dEj, dh):
                          _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(dEj), _lib.ptr(dh), _lib.ptr(dWT), _lib.ptr(dv), _lib.ptr(ws), ws_n,
                          _lib.stream_ptr()), "tgcn_attn_bwd")
     return dP, dWT, dv
+
+
+def attn_bwd_pulls(P, Q, WT, v, Ej, idx, widx, attn, d_out, addQ, addX, w_major=-1, out=None):
+    """The attention backward of one relation in pull form without the dh round trip (include/tagrec.h): the relation's
+    table of this step's rows is inverted on the spot (one radix sort of the n k destination ids; pads sort behind the last
+    row), then  dEj (+ addX) and da  <-  attn_pull_da;  dP, dWT, dv, (ds, relu bits)  <-  attn_bwd_ds;  dQ (+ addQ)  <-
+    attn_pull_dq.  out: where dEj is written (it may be addX itself).  Returns (dP, dWT, dv, dQ, dEj)."""
+    from . import tgcn as TG
+    from .graph import Graph
+    lib = _lib.load()
+    n, A = P.shape
+    k, n_wt = idx.shape[1], WT.shape[0]
+    n_dst, D = Ej.shape
+    dev = P.device
+    key = torch.empty(n * k, dtype=torch.int32, device=dev)
+    _lib.check(lib.tagrec_attn_keys_i32(_lib.ptr(idx), n * k, n_dst, _lib.ptr(key), _lib.stream_ptr()), "attn_keys")
+    skey, order = torch.sort(key, stable=True)
+    rowptr = torch.searchsorted(skey, torch.arange(n_dst + 1, dtype=torch.int32, device=dev))
+    pair = torch.empty(n * k, dtype=torch.int32, device=dev)
+    src = torch.empty(n * k, dtype=torch.int32, device=dev)
+    val = torch.empty(n * k, dtype=torch.float32, device=dev)
+    _lib.check(lib.tagrec_attn_invert_fill(_lib.ptr(order), _lib.ptr(attn), k, n * k, _lib.ptr(pair), _lib.ptr(src), _lib.ptr(val),
+                                           _lib.stream_ptr()), "attn_invert_fill")
+    inv = Graph(rowptr, src, val, (n_dst, n), workspace=True)
+    da = torch.empty(n * k, dtype=torch.float32, device=dev)
+    dEj = out if out is not None else torch.empty(n_dst, D, dtype=torch.float32, device=dev)      # (may alias addX: element-wise)
+    _lib.check(TG._timed("attn_pull_da", lib.tagrec_attn_pull_da_f32, inv.handle, _lib.ptr(pair), _lib.ptr(d_out), _lib.ptr(Ej),
+                         _lib.ptr(addX), _lib.ptr(dEj), _lib.ptr(da), D, _lib.stream_ptr()), "attn_pull_da")
+    dP = torch.empty_like(P)
+    dWT, dv = torch.empty_like(WT), torch.empty_like(v)
+    comp = torch.empty(n * k, 2, dtype=torch.float32, device=dev)
+    ws_n = lib.tagrec_tgcn_attn_workspace(n_wt, A)
+    ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+    _lib.check(TG._timed("attn_bwd", lib.tagrec_tgcn_attn_bwd_ds_f32, _lib.ptr(P), _lib.ptr(Q), _lib.ptr(WT), _lib.ptr(v), _lib.ptr(idx),
+                         _lib.ptr(widx), _lib.ptr(attn), _lib.ptr(da), n, k, A, n_wt, int(w_major), _lib.ptr(dP), _lib.ptr(comp), _lib.ptr(dWT),
+                         _lib.ptr(dv), _lib.ptr(ws), ws_n, _lib.stream_ptr()), "tgcn_attn_bwd_ds")
+    if SEGMENTED_DQ:         # balanced segmented sum over the sorted pair list, float atomics at segment ends (adds into addQ)
+        dQ = addQ if addQ is not None else torch.zeros(n_dst, A, dtype=torch.float32, device=dev)
+        _lib.check(TG._timed("attn_pull_dq", lib.tagrec_attn_seg_dq_f32, _lib.ptr(skey), _lib.ptr(pair), n * k, n_dst, _lib.ptr(comp),
+                             _lib.ptr(v), A, _lib.ptr(dQ), _lib.stream_ptr()), "attn_seg_dq")
+    else:                    # row-per-wave pull on the inverted table (deterministic order)
+        dQ = torch.empty(n_dst, A, dtype=torch.float32, device=dev)
+        inv = inv.like(pair, val, n * k)                    # the same rows, colidx = pair ids
+        _lib.check(TG._timed("attn_pull_dq", lib.tagrec_attn_pull_dq_f32, inv.handle, _lib.ptr(comp), _lib.ptr(v), A, _lib.ptr(addQ),
+                             _lib.ptr(dQ), _lib.stream_ptr()), "attn_pull_dq")
+    return dP, dWT, dv, dQ, dEj
 
 
 def fuse_fwd(t0, t1, t2, dp):
@@ -115,8 +163,11 @@ def tall_wgrad(X, dY):
 # ------------------------------------------------------------------------------------------------ the step
 def step_forward(model, batch, embs, ew, layers_ps, training_drop):
     """Forward of the restricted step.  embs: {type: table}; layers_ps: per layer the 21 detached parameters.
+    The three node types of a layer share ONE set of merged buffers -- rows [users | items | tags] of the layer's row
+    subsets -- so the fused dense block (and its backward and weight-gradient kernels) is launched once per layer, not
+    once per type: the small launches of the upper layers (a few thousand rows: a fraction of one wave of blocks) fill
+    more of the chip, and the next layer's input tables are row slices of the merged output.
     Returns (res [2], state)."""
-    from . import tgcn as TG
     dev = batch.device
     lib = _lib.load()
     need = model._needed_rows(batch)
@@ -130,7 +181,7 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
     cat = {t: torch.empty(n_top[t], dtot, dtype=torch.float32, device=dev) for t in ("user", "item")}
     for t in cat:
         cat[t][:, :dims[0]] = embs[t].index_select(0, top[t])
-    X = dict(embs)
+    X = {t: embs[t].contiguous() for t in TYPES}
     rows_in = {t: None for t in TYPES}
     pos_in = {t: None for t in TYPES}
     saved = []
@@ -139,58 +190,66 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
     for li, ps in enumerate(layers_ps):
         layer = model.layer[str(li)]
         D, A = layer.in_features, layer.U.shape[1]
-        att = {t: ps[4 * i:4 * i + 4] for i, t in enumerate(TYPES)}          # W_1, W_2, b, v
+        att = {t: [x.contiguous() for x in ps[4 * i:4 * i + 4]] for i, t in enumerate(TYPES)}          # W_1, W_2, b, v
         dp = _dense_views(ps[12:])
+        d_out = dims[li + 1]
         rows_out = need[li + 1]
-        st = {"rows_out": rows_out, "rows_in": rows_in, "X": X, "att": att, "dp": dp, "ewp": ewp}
+        own = PJ.supported(D, A, 2 * A)               # the projections on csrc/proj.hip (else the library GEMMs)
+        m = {t: (X[t].shape[0] if rows_out[t] is None else rows_out[t].numel()) for t in TYPES}
+        lo, M = {}, 0
+        for t in TYPES:
+            lo[t], M = M, M + m[t]
+        rng = {t: slice(lo[t], lo[t] + m[t]) for t in TYPES}
+        T3 = [torch.empty(M, D, dtype=torch.float32, device=dev) for _ in range(3)]      # (user-, item-, tag-side) vectors
+        st = {"rows_out": rows_out, "rows_in": rows_in, "X": X, "att": att, "dp": dp, "ewp": ewp, "own": own, "m": m, "rng": rng,
+              "M": M, "T3": T3}
         sel, Xs, Q, P = {}, {}, {}, {}
         for t, (n1, n2) in OTHERS.items():
+            Xs[t] = T3[SLOT[t]][rng[t]]                     # the rows' own vectors: the type's slot of the triple
             if rows_out[t] is None:
-                sel[t], Xs[t] = None, X[t]
+                sel[t] = None
+                Xs[t].copy_(X[t])
             else:
                 sel[t] = rows_out[t] if rows_in[t] is None else pos_in[t].index_select(0, rows_out[t] + 1).long() - 1
-                Xs[t] = X[t].index_select(0, sel[t])
-            Q[t] = X[t] @ att[t][1]
-            P[(t, n1)] = torch.addmm(att[n1][2], Xs[t], att[n1][0][:D])
-            P[(t, n2)] = torch.addmm(att[n2][2], Xs[t], att[n2][0][:D])
-        WT = {t: ewp @ att[t][0][D:] for t in TYPES}
+                if m[t]:
+                    torch.index_select(X[t], 0, sel[t], out=Xs[t])
+            if own:
+                Q[t] = PJ.tall_mm(X[t], att[t][1], torch.empty(X[t].shape[0], A, dtype=torch.float32, device=dev))
+                P[(t, n1)] = torch.empty(m[t], A, dtype=torch.float32, device=dev)
+                P[(t, n2)] = torch.empty(m[t], A, dtype=torch.float32, device=dev)
+                PJ.tall_mm(Xs[t], att[n1][0][:D], P[(t, n1)], W2=att[n2][0][:D], w_split=2, b1=att[n1][2], b2=att[n2][2],
+                           out2=P[(t, n2)])
+            else:
+                Q[t] = X[t] @ att[t][1]
+                P[(t, n1)] = torch.addmm(att[n1][2], Xs[t], att[n1][0][:D])
+                P[(t, n2)] = torch.addmm(att[n2][2], Xs[t], att[n2][0][:D])
+        WT = {t: (PJ.small_mm(ewp, att[t][0][D:]) if own else ewp @ att[t][0][D:]) for t in TYPES}
         st.update(sel=sel, Xs=Xs, Q=Q, P=P, WT=WT)
-        outs, attns, idxs = {}, {}, {}
+        attns, idxs = {}, {}
         for r, (src, nb) in enumerate(RELATIONS):
             rows = rows_out[src]
-            m = Xs[src].shape[0]
-            if m == 0:
-                outs[r] = X[nb].new_zeros(0, D)
+            if m[src] == 0:
                 continue
             idx = model.nbr[r][0] if rows is None else model.nbr[r][0].index_select(0, rows)
             widx = model.nbr[r][1] if rows is None else model.nbr[r][1].index_select(0, rows)
             if rows_in[nb] is not None:                      # neighbour ids -> positions in the compact table
                 idx = pos_in[nb].index_select(0, idx.flatten().long()).reshape(idx.shape)
-            outs[r], attns[r] = attn_fwd(P[(src, nb)], Q[nb], WT[nb], att[nb][3].reshape(-1), X[nb], idx, widx)
+            _, attns[r] = attn_fwd(P[(src, nb)], Q[nb], WT[nb], att[nb][3].reshape(-1), X[nb], idx, widx,
+                                   out=T3[SLOT[nb]][rng[src]])
             idxs[r] = (idx, widx)
-        st.update(outs=outs, attns=attns, idxs=idxs)
-        trips = {"user": (Xs["user"], outs[0], outs[1]), "item": (outs[2], Xs["item"], outs[3]),
-                 "tag": (outs[4], outs[5], Xs["tag"])}
-        O, BW = {}, {}
-        for t, trip in trips.items():
-            if trip[0].shape[0] > 0:
-                O[t], BW[t] = fuse_fwd(trip[0].contiguous(), trip[1], trip[2], dp)
-            else:
-                O[t], BW[t] = trip[0].new_zeros(0, dp[7].shape[1]), None
-        st.update(O=O, BW=BW)
+        st.update(attns=attns, idxs=idxs)
+        O_all, BW_all = fuse_fwd(T3[0], T3[1], T3[2], dp)
+        st.update(O=O_all, BW=BW_all)
         # message dropout of the layer's outputs (tgcn.py:217-219): the library's counter-based mask keyed by NODE id
         pk = drops[li] if drops else 0.0
-        Od = O
+        Od_all = O_all
         if pk > 0:
-            Od = {}
+            Od_all = torch.empty_like(O_all)
             for t in TYPES:
-                if O[t].shape[0] == 0:
-                    Od[t] = O[t]
-                elif rows_out[t] is None:
-                    Od[t] = H.message_drop(O[t], pk, _drop_seed(seed, li, t))
-                else:
-                    Od[t] = H.message_drop(O[t], pk, _drop_seed(seed, li, t), rows=rows_out[t])
+                if m[t]:
+                    H.message_drop(O_all[rng[t]], pk, _drop_seed(seed, li, t), out=Od_all[rng[t]], rows=rows_out[t])
         st["pk"] = pk
+        Od = {t: Od_all[rng[t]] for t in TYPES}
         # positions of the batch rows in this layer's output, their normalised rows into the concat buffer
         pos_out, extra = {}, {}
         for t in TYPES:
@@ -198,7 +257,6 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
             if rows_out[t] is not None:
                 pos_out[t] = torch.zeros(sizes[t] + 1, dtype=torch.int32, device=dev)
                 pos_out[t][rows_out[t] + 1] = torch.arange(1, rows_out[t].numel() + 1, dtype=torch.int32, device=dev)
-        d_out = dims[li + 1]
         norm_saved = {}
         for t in cat:
             extra[t] = top[t] if rows_out[t] is None else pos_out[t].index_select(0, top[t] + 1).long() - 1
@@ -243,135 +301,156 @@ def step_backward(model, g, state, n_weight):
     L = len(saved)
     layer_grads = [None] * L
     d_ewp = None
-    G = None                  # {type: gradient w.r.t. the output rows of the layer being processed}
+    G_all = None              # gradient w.r.t. the merged output rows of the layer being processed (written by the layer above)
+    d_tables = None
     for li in range(L - 1, -1, -1):
         st = saved[li]
         layer = model.layer[str(li)]
         D, A = layer.in_features, layer.U.shape[1]
         att, dp, ewp = st["att"], st["dp"], st["ewp"]
-        rows_out, rows_in, X, Xs, sel = st["rows_out"], st["rows_in"], st["X"], st["Xs"], st["sel"]
-        O, pk = st["O"], st["pk"]
+        rows_out, X, Xs, sel, m, rng, M, T3 = (st[k_] for k_ in ("rows_out", "X", "Xs", "sel", "m", "rng", "M", "T3"))
+        pk = st["pk"]
         # gradient w.r.t. the (dropped) output rows: what the layer above sent down + the loss's normalised batch rows
-        Gd = {}
-        for t in TYPES:
-            m = O[t].shape[0]
-            gt = G[t] if (G is not None and G.get(t) is not None) else None
-            if t in cat and m > 0 and cat[t].shape[0] > 0:
+        if G_all is None:
+            G_all = torch.zeros(M, dims[li + 1], dtype=torch.float32, device=dev)
+        for t in cat:
+            if m[t] and cat[t].shape[0]:
                 xr, inv = st["norm"][t]
-                nb_rows = xr.shape[0]
                 dz = torch.empty_like(xr)
                 _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(xr), _lib.ptr(inv), _lib.ptr(d_cat[t][:, st["off"]:]), dtot, 1.0,
-                                                      _lib.ptr(dz), 0, nb_rows, xr.shape[1], _lib.stream_ptr()), "rownorm_bwd")
-                if gt is None:
-                    if nb_rows == m:              # the top layer: its rows ARE the batch rows, in order
-                        gt = dz
-                    else:
-                        gt = torch.zeros(m, xr.shape[1], dtype=torch.float32, device=dev)
-                        gt.index_add_(0, st["extra"][t], dz)
-                else:
-                    gt.index_add_(0, st["extra"][t], dz)
-            if gt is None:
-                gt = torch.zeros(m, dims[li + 1], dtype=torch.float32, device=dev)
-            if pk > 0 and m > 0:                  # through the dropout mask (same mask as the forward's)
-                gt = gt.contiguous()
-                H.message_drop(gt, pk, _drop_seed(state["seed"], li, t), out=gt, rows=rows_out[t])
-            Gd[t] = gt
-        # ---- fused dense block: input gradients per type, weight gradients summed over the three types
-        trips = {"user": (Xs["user"], st["outs"][0], st["outs"][1]), "item": (st["outs"][2], Xs["item"], st["outs"][3]),
-                 "tag": (st["outs"][4], st["outs"][5], Xs["tag"])}
-        dts, dense_g = {}, None
-        for t, tr in trips.items():
-            if tr[0].shape[0] == 0:
-                continue
-            r = TG._FusedDense._backward_rows(tr[0].contiguous(), tr[1], tr[2], *dp[:8], O[t], st["BW"][t], Gd[t].contiguous())
-            dts[t] = r[:3]
-            dense_g = list(r[3:12]) if dense_g is None else [a + b for a, b in zip(dense_g, r[3:12])]
-        if dense_g is None:
-            dense_g = [torch.zeros_like(x) for x in dp]
-        # ---- neighbour attentions: scatter-form relations first (into zeroed buffers), then the pull-form ones, each adding
-        # what has been collected so far in its product's epilogue
-        accX = {t: None for t in TYPES}
+                                                      _lib.ptr(dz), 0, xr.shape[0], xr.shape[1], _lib.stream_ptr()), "rownorm_bwd")
+                G_all[rng[t]].index_add_(0, st["extra"][t], dz)          # (the batch rows of a type are distinct)
+        if pk > 0:                                # through the dropout mask (same mask as the forward's)
+            for t in TYPES:
+                if m[t]:
+                    H.message_drop(G_all[rng[t]], pk, _drop_seed(state["seed"], li, t), out=G_all[rng[t]], rows=rows_out[t])
+        # ---- fused dense block, the three types in one launch: input gradients + its weight gradients
+        r_ = TG._FusedDense._backward_rows(T3[0], T3[1], T3[2], *dp[:8], st["O"], st["BW"], G_all)
+        dts_all, dense_g = r_[:3], list(r_[3:12])
+        G_all = None
+        # where this layer's input gradients go: row slices of ONE merged buffer (= the output gradient of the layer below),
+        # or, at the bottom, one buffer per embedding table
+        n_in = {t: X[t].shape[0] for t in TYPES}
+        if li > 0:
+            below = saved[li - 1]
+            dX_all = torch.empty(below["M"], D, dtype=torch.float32, device=dev)
+            dx = {t: dX_all[below["rng"][t]] for t in TYPES}
+        else:
+            dX_all = None
+            dx = {t: torch.empty(n_in[t], D, dtype=torch.float32, device=dev) for t in TYPES}
+        have_x = {t: False for t in TYPES}        # dx[t] holds something yet?
         accQ = {t: None for t in TYPES}
         dP = {}
         dW1 = {t: torch.zeros_like(att[t][0]) for t in TYPES}
         db = {t: torch.zeros_like(att[t][2]) for t in TYPES}
         dv = {t: torch.zeros_like(att[t][3]) for t in TYPES}
         dWTs = {t: None for t in TYPES}
-        n_in = {t: X[t].shape[0] for t in TYPES}
-        order = sorted(range(6), key=lambda r: (Xs[RELATIONS[r][0]].shape[0] >= TG._PULL_MIN_ROWS, r))
+        # ---- neighbour attentions: scatter-form relations first (into zeroed buffers), then the pull-form ones, each adding
+        # what has been collected so far in its product's epilogue
+        order = sorted(range(6), key=lambda r: (m[RELATIONS[r][0]] >= TG._PULL_MIN_ROWS, r))
         for r in order:
             src, nb = RELATIONS[r]
-            m = Xs[src].shape[0]
-            if m == 0:
+            if m[src] == 0:
                 continue
-            d_out = dts[src][SLOT[nb]]
+            d_out = dts_all[SLOT[nb]][rng[src]]
             idx, widx = st["idxs"][r]
-            pull = m >= TG._PULL_MIN_ROWS
+            pull = m[src] >= TG._PULL_MIN_ROWS
             k = idx.shape[1]
-            if pull:
-                dh = torch.empty(m * k, A, dtype=torch.float32, device=dev)
-                dQ = dEj = None
+            if pull and A in (16, 32):
+                # destination-centric pull of dEj (+ da on the way), source-centric softmax backward from da (8 bytes per pair
+                # out), destination-centric pull of dQ from the compressed pairs
+                dP[r], dWT_r, dv_r, accQ[nb], _ = attn_bwd_pulls(
+                    st["P"][(src, nb)], st["Q"][nb], st["WT"][nb], att[nb][3].reshape(-1), X[nb], idx, widx, st["attns"][r], d_out,
+                    accQ[nb], dx[nb] if have_x[nb] else None, model.w_major[r], out=dx[nb])
+                have_x[nb] = True
             else:
-                dh = None
-                if accX[nb] is None:
-                    accX[nb] = torch.zeros(n_in[nb], D, dtype=torch.float32, device=dev)
-                if accQ[nb] is None:
-                    accQ[nb] = torch.zeros(n_in[nb], A, dtype=torch.float32, device=dev)
-                dQ, dEj = accQ[nb], accX[nb]
-            dP[r], dWT_r, dv_r = attn_bwd(st["P"][(src, nb)], st["Q"][nb], st["WT"][nb], att[nb][3].reshape(-1), X[nb], idx, widx,
-                                          st["attns"][r], d_out, dQ, dEj, dh)
+                if pull:
+                    dh = torch.empty(m[src] * k, A, dtype=torch.float32, device=dev)
+                    dQ = dEj = None
+                else:
+                    dh = None
+                    if not have_x[nb]:
+                        dx[nb].zero_()
+                        have_x[nb] = True
+                    if accQ[nb] is None:
+                        accQ[nb] = torch.zeros(n_in[nb], A, dtype=torch.float32, device=dev)
+                    dQ, dEj = accQ[nb], dx[nb]
+                dP[r], dWT_r, dv_r = attn_bwd(st["P"][(src, nb)], st["Q"][nb], st["WT"][nb], att[nb][3].reshape(-1), X[nb], idx, widx,
+                                              st["attns"][r], d_out, dQ, dEj, dh)
+                if pull:
+                    accQ[nb], px = _pull_add(idx, st["attns"][r], d_out, dh, n_in[nb], accQ[nb], dx[nb] if have_x[nb] else None)
+                    dx[nb].copy_(px)
+                    have_x[nb] = True
             dWTs[nb] = dWT_r if dWTs[nb] is None else dWTs[nb] + dWT_r
             dv[nb] = dv[nb] + dv_r.reshape(dv[nb].shape)
-            if pull:
-                accQ[nb], accX[nb] = _pull_add(idx, st["attns"][r], d_out, dh, n_in[nb], accQ[nb], accX[nb])
         # ---- projections backward
-        dXout = {}
+        own = st["own"]
+        dW2s = {}
         for t, (n1, n2) in OTHERS.items():
             r1, r2 = RELATIONS.index((t, n1)), RELATIONS.index((t, n2))
             dXs = None
-            if t in dts:
-                dXs = dts[t][SLOT[t]]
-                for r_, n_ in ((r1, n1), (r2, n2)):
-                    dXs.addmm_(dP[r_], att[n_][0][:D].t())
-                    dW1[n_][:D] += tall_wgrad(Xs[t], dP[r_])
-                    db[n_] += dP[r_].sum(0, keepdim=True)
-            dx = accX[t]
-            if accQ[t] is not None:
-                if dx is None:
-                    dx = accQ[t] @ att[t][1].t()
+            if m[t]:
+                dXs = dts_all[SLOT[t]][rng[t]]
+                if own:
+                    PJ.tall_mm(dP[r1], att[n1][0][:D], dXs, X2=dP[r2], W2=att[n2][0][:D], w_split=1, transposed=True, accumulate=True)
+                    dW = PJ.tall_wgrad(Xs[t], dP[r1], dP[r2], db1=db[n1], db2=db[n2], acc_b=True)
+                    dW1[n1][:D] += dW[:, :A]
+                    dW1[n2][:D] += dW[:, A:]
                 else:
-                    dx.addmm_(accQ[t], att[t][1].t())
-                dW2 = tall_wgrad(X[t], accQ[t])
+                    for r_i, n_ in ((r1, n1), (r2, n2)):
+                        dXs.addmm_(dP[r_i], att[n_][0][:D].t())
+                        dW1[n_][:D] += tall_wgrad(Xs[t], dP[r_i])
+                        db[n_] += dP[r_i].sum(0, keepdim=True)
+            if accQ[t] is not None:
+                if own:
+                    PJ.tall_mm(accQ[t], att[t][1], dx[t], transposed=True, accumulate=have_x[t])
+                    dW2s[t] = PJ.tall_wgrad(X[t], accQ[t])
+                else:
+                    if have_x[t]:
+                        dx[t].addmm_(accQ[t], att[t][1].t())
+                    else:
+                        torch.mm(accQ[t], att[t][1].t(), out=dx[t])
+                    dW2s[t] = tall_wgrad(X[t], accQ[t])
+                have_x[t] = True
             else:
-                dW2 = torch.zeros_like(att[t][1])
-            if dx is None:
-                dx = torch.zeros(n_in[t], D, dtype=torch.float32, device=dev)
+                dW2s[t] = torch.zeros_like(att[t][1])
+            if not have_x[t]:
+                dx[t].zero_()
             if dXs is not None:
                 if sel[t] is None:
-                    dx += dXs
+                    dx[t] += dXs
+                elif own:
+                    PJ.row_add_at(dx[t], sel[t], dXs)
                 else:
-                    dx.index_add_(0, sel[t], dXs)
-            dXout[t] = dx
-            st["dW2_" + t] = dW2
+                    dx[t].index_add_(0, sel[t], dXs)
             if dWTs[t] is not None:
-                dW1[t][D:] += ewp.t() @ dWTs[t]
-                contrib = dWTs[t] @ att[t][0][D:].t()
-                d_ewp = contrib if d_ewp is None else d_ewp + contrib
+                if own:
+                    PJ.small_mm(ewp.t(), dWTs[t], out=dW1[t][D:], accumulate=True)
+                    if d_ewp is None:
+                        d_ewp = PJ.small_mm(dWTs[t], att[t][0][D:].t())
+                    else:
+                        PJ.small_mm(dWTs[t], att[t][0][D:].t(), out=d_ewp, accumulate=True)
+                else:
+                    dW1[t][D:] += ewp.t() @ dWTs[t]
+                    contrib = dWTs[t] @ att[t][0][D:].t()
+                    d_ewp = contrib if d_ewp is None else d_ewp + contrib
         lg = []
         for t in TYPES:
-            lg += [dW1[t], st["dW2_" + t], db[t], dv[t]]
-        U_, q_, p_, wb_, w1_, w2_, w3_, Wf_, bf_ = dense_g
+            lg += [dW1[t], dW2s[t], db[t], dv[t]]
         shapes = [x.shape for x in layer_params(layer)[12:]]
-        lg += [x.reshape(s) for x, s in zip((U_, q_, p_, wb_, w1_, w2_, w3_, Wf_, bf_), shapes)]
+        lg += [x.reshape(s_) for x, s_ in zip(dense_g, shapes)]
         layer_grads[li] = lg
         saved[li] = None
-        G = dXout
+        if li > 0:
+            G_all = dX_all
+        else:
+            d_tables = dx
     # embedding tables: layer 0's input gradient + the ego slot of the concat at the batch rows
     for t in cat:
         if cat[t].shape[0]:
-            G[t].index_add_(0, top[t], d_cat[t][:, :dims[0]])
+            d_tables[t].index_add_(0, top[t], d_cat[t][:, :dims[0]])
     d_weight = d_ewp[1:] if d_ewp is not None else torch.zeros(n_weight, model.dim_weight, device=dev)
-    flat = [G["user"], G["item"], G["tag"], d_weight]
+    flat = [d_tables["user"], d_tables["item"], d_tables["tag"], d_weight]
     for lg in layer_grads:
         flat += lg
     return flat

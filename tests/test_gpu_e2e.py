@@ -340,3 +340,46 @@ def test_basic_test_fused_equals_batched_path():
     slow = T.Basic_test(ds, config=dict(cfg, eval_fused=False), with_auc=False).run(model)
     for k in ("recall", "precision", "hr", "ndcg"):
         np.testing.assert_allclose(fused[k], slow[k], rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+def test_full_size_c4_training_step_restricted_equals_all_rows():
+    """BASELINE.json configs[3] at FULL size (1 M users, 1 M items, 2 M tags, ~100 M assignments, D = 128, k = 25, 3 layers):
+    one BPR step of the hand-derived step node (layers restricted to the rows the batch's loss depends on, compact tables,
+    pull-form attention backward, own projections) against the all-rows step (`forward()` on 4 M nodes + autograd): same
+    loss parts, same gradient of every parameter.  Sums run over different row sets / orders and the backward uses float
+    atomics in places, so tensors are compared as a whole: ||a - b|| <= 2e-3 ||a|| + 1e-5 max ||.|| (the floor: the dense
+    block's weight gradients of the upper layers are ~1e-8 here -- sums over up to 4 M rows of +-1e-3 terms that cancel --
+    and both passes carry ~1e-9 of fp32 accumulation noise, measured 1.0e-9 .. 2.6e-9 against max ||.|| = 5e-4)."""
+    torch.cuda.empty_cache()
+    ds = T.synth.make_tripartite_device(1_000_000, 1_000_000, 2_000_000, 100_000_000, seed=2, device=DEV)
+    cfg = T.get_config("tgcn", dim_latent=128, dim_layer_list=[128, 128, 128], device=DEV, train_batch=512, neighbor_k=25, reg=1e-4)
+    torch.manual_seed(cfg["seed"])
+    m = T.TGCN(ds, config=cfg)
+    m.train()
+    assert m.prune_forward and m.step_node and m._step_node_ok()
+    batch = T.BPR_training_data(ds, config=cfg, seed=2020).all_train_data[:512]
+    need = m._needed_rows(batch)
+    assert need[1]["user"] is not None and 100_000 < need[1]["user"].numel() < 600_000      # the restricted step IS restricted
+    res = []
+    for restricted in (True, False):
+        m.prune_forward = restricted
+        m.zero_grad(set_to_none=True)
+        lossx = m.loss(batch)
+        sum(lossx).backward()
+        res.append(([float(v.detach()) for v in lossx], {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+        for p in m.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+    (l1, g1), (l0, g0) = res
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)
+    assert set(g0) == set(g1) and len(g0) == 4 + 3 * 21
+    norms = {k: float(g0[k].double().norm()) for k in g0}
+    top = max(norms.values())
+    bad = {}
+    for k in g0:
+        err = float((g0[k].double() - g1[k].double()).norm())
+        if not err <= 2e-3 * norms[k] + 1e-5 * top:
+            bad[k] = (err, norms[k])
+    assert not bad, (top, bad)
+    del m, ds, res, g0, g1
+    torch.cuda.empty_cache()

@@ -521,6 +521,44 @@ def test_compact_pull_backward_with_a_popular_neighbour():
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=3e-6 * scale)
 
 
+@pytest.mark.parametrize("n,n_nbr,k,D,A", [(6000, 500, 5, 32, 32), (3000, 4000, 25, 128, 32), (2000, 100, 64, 64, 16), (70, 9, 3, 256, 32)])
+def test_attention_backward_pulls_without_dh_equal_the_scatter_form(n, n_nbr, k, D, A):
+    """The three-launch pull form of the attention backward (tagrec_attn_pull_da_f32 -> tagrec_tgcn_attn_bwd_ds_f32 ->
+    tagrec_attn_pull_dq_f32: da formed by the destination-centric pull, 8 bytes per pair between the source- and the
+    destination-centric halves) against the float-atomic scatter form of tagrec_tgcn_attn_bwd_f32: dP, dWT, dv, dQ, dEj,
+    with pads, a destination that collects more than 1024 pairs (long row), destinations nobody points at, and the
+    add-what-was-collected-so-far epilogues."""
+    from tagrec_amd import tgcn_step as TS
+    n_wt = 4
+    gen = torch.Generator(device="cpu").manual_seed(n + k)
+    rnd = lambda *s_: (torch.randn(*s_, generator=gen) * 0.3).to(DEV)
+    idx = torch.randint(0, n_nbr + 1, (n, k), generator=gen)
+    idx[:, 0] = 7                                             # every node lists destination 6 -> a long row when n > 1024
+    idx[::3, 1 % k] = 0                                       # pads
+    idx[idx == n_nbr] = 1                                     # destination n_nbr - 1 is never pointed at
+    idx32 = idx.to(DEV).to(torch.int32).contiguous()
+    widx32 = torch.randint(0, n_wt, (n, k), generator=gen).to(DEV).to(torch.int32)
+    P, Q, WT, v, Ej = rnd(n, A), rnd(n_nbr, A), rnd(n_wt, A), rnd(A), rnd(n_nbr, D)
+    d_out = rnd(n, D)
+    _, attn = TS.attn_fwd(P, Q, WT, v, Ej, idx32, widx32)
+    dQ0, dEj0 = torch.zeros(n_nbr, A, device=DEV), torch.zeros(n_nbr, D, device=DEV)
+    dP0, dWT0, dv0 = TS.attn_bwd(P, Q, WT, v, Ej, idx32, widx32, attn, d_out, dQ0, dEj0, None)
+    addQ, addX = rnd(n_nbr, A), rnd(n_nbr, D)
+    old = TS.SEGMENTED_DQ
+    try:
+        for seg in (True, False):              # dQ by the segmented sum over the sorted pairs / by the row-per-wave pull
+            TS.SEGMENTED_DQ = seg
+            for aq, ax in ((None, None), (addQ, addX)):
+                dP1, dWT1, dv1, dQ1, dEj1 = TS.attn_bwd_pulls(P, Q, WT, v, Ej, idx32, widx32, attn, d_out,
+                                                              None if aq is None else aq.clone(), ax, w_major=1 if seg else -1)
+                want = [dP0, dWT0, dv0, dQ0 if aq is None else dQ0 + aq, dEj0 if ax is None else dEj0 + ax]
+                for name, a, b in zip(("dP", "dWT", "dv", "dQ", "dEj"), want, (dP1, dWT1, dv1, dQ1, dEj1)):
+                    scale = float(a.abs().max()) + 1e-30
+                    np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=3e-6 * scale, err_msg=f"{name} seg={seg}")
+    finally:
+        TS.SEGMENTED_DQ = old
+
+
 def test_tall_projection_weight_gradient_by_slabs():
     """`_TallMM`: X @ W whose weight gradient is summed slab by slab (n not a multiple of the slab count)."""
     from tagrec_amd import tgcn as TG

@@ -448,8 +448,11 @@ def test_fused_adam_ownership_and_commit():
     `fused_commit` (after the launch), not by `fused_state`."""
     ds = T.synth.make_bipartite_device(6000, 5000, 200_000, seed=11, device=DEV)
     cfg = T.get_config("lightgcn", use_tag=False, dim_layer_list=[32, 32], dim_latent=32, device=DEV, train_batch=64)
+    e = ds.edge_index["train"]
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 6000, 5000, "bi_norm")
+    g = T.Graph(rp, col, val, (n, n), symmetric=True)
     torch.manual_seed(3)
-    m = T.LightGCN(ds, config=cfg)
+    m = T.LightGCN(ds, config=cfg, graph=g)
     m.train()
     b = T.BPR_training_data(ds, config=cfg, seed=9).all_train_data[:64]
     old = T.Adam(m.parameters(), lr=0.5).fuse_into(m)
@@ -466,7 +469,7 @@ def test_fused_adam_ownership_and_commit():
     assert m.table.grad is not None and torch.equal(m.table.detach(), before)
     new.step()
     assert float((m.table.detach() - before).abs().max()) <= 0.0100001        # moved with the NEW lr (Adam: |step| <= lr)
-    other = T.LightGCN(ds, config=cfg)
+    other = T.LightGCN(ds, config=cfg, graph=g)
     with pytest.raises(T._lib.TagrecError, match="not one of this optimizer"):
         new.fuse_into(other)
     # fused_state alone leaves no mark
@@ -476,3 +479,79 @@ def test_fused_adam_ownership_and_commit():
     new.fused_commit(m.table)
     with pytest.raises(T._lib.TagrecError, match="second backward"):
         new.fused_state(m.table)
+
+
+@pytest.mark.parametrize("name", ["lightgcn", "ngcf"])
+def test_restricted_step_reads_no_unwritten_row_model_level_poison(name, monkeypatch):
+    """The single-GPU restricted LightGCN / NGCF step leaves the rows a layer does not compute UNWRITTEN in torch.empty
+    buffers and tells every later reader which rows are valid (row masks, always-consulted operand flags, dz_flags).  Here
+    every float buffer the step allocates with torch.empty / empty_like / Tensor.new_empty is pre-filled with NaN (the
+    allocator hands back blocks with stale finite values otherwise, which would hide a stale read): at 50 k nodes the loss,
+    the gradients -- and with the optimizer fused into the last hop the updated table and Adam state -- must be finite and
+    equal to the all-rows step's."""
+    ds = T.synth.make_bipartite_device(25_000, 25_000, 1_000_000, seed=13, device=DEV)
+    e = ds.edge_index["train"]
+    norm = "bi_norm" if name == "lightgcn" else "ngcf"
+    rp, col, val, n = T.graph.bipartite_norm_device(e[:, 0], e[:, 1], 25_000, 25_000, norm)
+    g = T.Graph(rp, col, val, (n, n), symmetric=(name == "lightgcn"))
+    g.transpose()
+    cls = {"lightgcn": T.LightGCN, "ngcf": T.NGCF}[name]
+    cfg = T.get_config(name, use_tag=False, dim_layer_list=[64, 64, 64], dim_latent=64, device=DEV, train_batch=128)
+    batch = T.BPR_training_data(ds, config=cfg, seed=3).all_train_data[:128]
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+
+    def poisoned_empty(*a, **kw):
+        t = real_empty(*a, **kw)
+        return t.fill_(float("nan")) if t.is_floating_point() and t.is_cuda else t
+
+    def poisoned_empty_like(*a, **kw):
+        t = real_empty_like(*a, **kw)
+        return t.fill_(float("nan")) if t.is_floating_point() and t.is_cuda else t
+
+    def run(poison, restrict, fuse):
+        torch.manual_seed(5)
+        if name == "ngcf":
+            from tagrec_amd import ngcf as NG
+            NG.RESTRICT_FORWARD = restrict
+        m = cls(ds, config=dict(cfg, restrict_forward=restrict), graph=g)
+        m.train()
+        opt = T.Adam(m.parameters(), lr=0.01)
+        if fuse:
+            opt.fuse_into(m)
+        if poison:
+            monkeypatch.setattr(torch, "empty", poisoned_empty)
+            monkeypatch.setattr(torch, "empty_like", poisoned_empty_like)
+        try:
+            lossx = m.loss(batch)
+            opt.zero_grad()
+            sum(lossx).backward()
+            grads = {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()}
+            opt.step()
+        finally:
+            monkeypatch.undo()
+        state = {k: p.detach().clone() for k, p in m.named_parameters()}
+        adam = [opt.state[id(p)][kk].clone() for p in m.parameters() for kk in ("m", "v")]
+        return [float(v.detach()) for v in lossx], grads, state, adam
+
+    try:
+        base = run(False, False, False)                  # all-rows step, nothing poisoned
+        for fuse in (False, True):
+            got = run(True, True, fuse)                  # restricted step, every torch.empty poisoned
+            np.testing.assert_allclose(got[0], base[0], rtol=1e-5)
+            for k in base[2]:
+                assert torch.isfinite(got[2][k]).all(), k
+                # (the first Adam step moves an element by lr * g / (|g| + 1e-8): last-bit differences of a near-zero gradient
+                # become visible, so a handful of elements may differ by more than 2e-4 -- never by more than 2 lr)
+                diff = (got[2][k] - base[2][k]).abs()
+                assert float((diff <= 2e-4).float().mean()) >= 0.999 and float(diff.max()) <= 0.0201, k
+            for a, b in zip(got[3], base[3]):
+                assert torch.isfinite(a).all()
+            if not fuse:
+                for k, gb in base[1].items():
+                    assert got[1][k] is not None and torch.isfinite(got[1][k]).all(), k
+                    scale = float(gb.abs().max()) + 1e-30
+                    np.testing.assert_allclose(got[1][k].cpu().numpy(), gb.cpu().numpy(), rtol=2e-3, atol=2e-5 * scale, err_msg=k)
+    finally:
+        if name == "ngcf":
+            from tagrec_amd import ngcf as NG
+            NG.RESTRICT_FORWARD = True
