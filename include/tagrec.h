@@ -486,6 +486,11 @@ int tagrec_tall_wgrad_f32(const float* X, const float* dY1, const float* dY2, in
 int tagrec_small_mm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak,
                         int64_t sbk, int64_t sbn, int accumulate, void* stream);
 int tagrec_row_add_at_f32(float* dst, const int64_t* pos, const float* src, int64_t n_rows, int D, void* stream);
+/*   masked_colsum : result[D] = column sums of dOut (.) [out > 0] -- the bias gradient of a ReLU layer (dbf of the fusion
+ *   layer, tgcn.py:104-106); per-block partials in `workspace` (tagrec_masked_colsum_workspace(D) floats), fixed-order fold. */
+int64_t tagrec_masked_colsum_workspace(int D);
+int tagrec_masked_colsum_f32(const float* dOut, const float* out, int64_t n_rows, int D, float* result, float* workspace,
+                             int64_t workspace_floats, void* stream);
 
 /* ---- bandwidth probes (measured ceilings of the box next to the 8 TB/s specification) ----------------
  * a = b + s * c over n floats (stream triad; 12 bytes per element), and a random whole-row gather with the access shape

@@ -136,6 +136,8 @@ _SIGNATURES = {
     "tagrec_tall_wgrad_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_int64, c_void_p],
     "tagrec_small_mm_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p],
+    "tagrec_masked_colsum_workspace": [c_int],
+    "tagrec_masked_colsum_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p],
     "tagrec_row_add_at_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "tagrec_probe_triad_f32": [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p],
     "tagrec_probe_gather_out_floats": [],

@@ -210,6 +210,30 @@ __global__ __launch_bounds__(256) void row_add_at_kernel(float* __restrict__ dst
   }
 }
 
+// column sums of dOut (.) [out > 0]: the bias gradient of a ReLU layer (tgcn.py:104-106, dbf of the fusion layer).
+// 256 threads = (256 / (D/4)) row lanes x D/4 float4 columns; per-block partials [blocks, D] folded by proj_fold_kernel.
+__global__ __launch_bounds__(256) void masked_colsum_kernel(const float* __restrict__ dOut, const float* __restrict__ outv, int64_t n,
+                                                             int d4, float* __restrict__ slab) {
+  __shared__ pj4 sh[256];
+  const int rpp = 256 / d4;                             // rows per pass of the block
+  const int c = threadIdx.x % d4, ty = threadIdx.x / d4;
+  pj4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (ty < rpp)
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * rpp + ty; r < n; r += static_cast<int64_t>(gridDim.x) * rpp) {
+      const pj4 g = __builtin_nontemporal_load(reinterpret_cast<const pj4*>(dOut) + r * d4 + c);
+      const pj4 o = __builtin_nontemporal_load(reinterpret_cast<const pj4*>(outv) + r * d4 + c);
+      acc.x += o.x > 0.f ? g.x : 0.f; acc.y += o.y > 0.f ? g.y : 0.f; acc.z += o.z > 0.f ? g.z : 0.f; acc.w += o.w > 0.f ? g.w : 0.f;
+    }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (ty == 0) {
+    pj4 t = sh[c];
+    for (int y = 1; y < rpp; ++y) t += sh[y * d4 + c];                 // fixed order
+    reinterpret_cast<pj4*>(slab)[static_cast<int64_t>(blockIdx.x) * d4 + c] = t;
+  }
+}
+
+constexpr int kColsumBlocks = 1024;
 constexpr int kWgradWaveCap = 2048;
 
 int64_t wgrad_waves(int64_t n, int64_t* steps_per_wave) {
@@ -345,6 +369,27 @@ extern "C" int tagrec_row_add_at_f32(float* dst, const int64_t* pos, const float
   int64_t blocks = (n_rows * (D / 4) + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   row_add_at_kernel<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(dst, pos, src, n_rows, D / 4);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int64_t tagrec_masked_colsum_workspace(int D) { return static_cast<int64_t>(kColsumBlocks) * D; }
+
+extern "C" int tagrec_masked_colsum_f32(const float* dOut, const float* out, int64_t n_rows, int D, float* result, float* workspace,
+                                        int64_t workspace_floats, void* stream) {
+  TAGREC_REQUIRE(n_rows >= 0 && D >= 4 && D % 4 == 0 && D <= 1024 && 256 % (D / 4) == 0, "masked_colsum: D / 4 must divide 256");
+  TAGREC_REQUIRE(result && workspace && (n_rows == 0 || (dOut && out)), "masked_colsum: null pointer");
+  TAGREC_REQUIRE(workspace_floats >= tagrec_masked_colsum_workspace(D), "masked_colsum: workspace too small");
+  TAGREC_REQUIRE(aligned16(dOut) && aligned16(out) && aligned16(workspace), "masked_colsum: 16-byte aligned rows expected");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rpp = 256 / (D / 4);
+  int64_t blocks = (n_rows + rpp - 1) / rpp;
+  if (blocks > kColsumBlocks) blocks = kColsumBlocks;
+  if (blocks > 0) {
+    masked_colsum_kernel<<<static_cast<unsigned>(blocks), 256, 0, s>>>(dOut, out, n_rows, D / 4, workspace);
+    TAGREC_LAUNCH_CHECK();
+  }
+  proj_fold_kernel<<<(D + 63) / 64, 1024, 0, s>>>(workspace, static_cast<int>(blocks), D, D, 0, result, nullptr, 0, 0, D, nullptr);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

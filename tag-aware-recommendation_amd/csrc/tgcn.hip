@@ -42,20 +42,32 @@ __device__ __forceinline__ float attention_weights(const float* __restrict__ p, 
   const int npi = kWave / A, grp = lane / A, c = lane % A;
   const float pc = p[c], vc = vv[c];
   float s = -INFINITY;
-  for (int n0 = 0; n0 < k; n0 += npi) {
-    const int n = n0 + grp;
-    const int jn = __shfl(j, n & (kWave - 1));
-    const int wn = __shfl(w, n & (kWave - 1));
-    float t = 0.f;
-    if (n < k) {
-      float h = pc + WT[static_cast<int64_t>(wn) * A + c];
-      if (jn) h += Q[static_cast<int64_t>(jn - 1) * A + c];
-      t = fmaxf(h, 0.f) * vc;
+  // UB steps at a time: their Q / WT reads are all issued before the first is used (a wave walks one node, and the steps
+  // were a chain of dependent memory latencies)
+  constexpr int UB = 8;
+  for (int n1 = 0; n1 < k; n1 += UB * npi) {
+    float hq[UB], hw[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int n = n1 + u * npi + grp;
+      const int jn = __shfl(j, n & (kWave - 1));
+      const int wn = __shfl(w, n & (kWave - 1));
+      const bool in = n < k;
+      hw[u] = in ? WT[static_cast<int64_t>(wn) * A + c] : 0.f;
+      hq[u] = (in && jn) ? Q[static_cast<int64_t>(jn - 1) * A + c] : 0.f;
     }
-    for (int m = 1; m < A; m <<= 1) t += __shfl_xor(t, m);
-    for (int gg = 0; gg < npi; ++gg) {
-      const float tg = __shfl(t, gg * A);
-      if (lane == n0 + gg && lane < k) s = tg;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int n0 = n1 + u * npi;
+      if (n0 < k) {                                    // (wave-uniform)
+        const int n = n0 + grp;
+        float t = n < k ? fmaxf(pc + hw[u] + hq[u], 0.f) * vc : 0.f;
+        for (int m = 1; m < A; m <<= 1) t += __shfl_xor(t, m);
+        for (int gg = 0; gg < npi; ++gg) {
+          const float tg = __shfl(t, gg * A);
+          if (lane == n0 + gg && lane < k) s = tg;
+        }
+      }
     }
   }
   const float mx = wave_max(s);
@@ -83,13 +95,22 @@ __global__ __launch_bounds__(kAttnThreads) void tgcn_attn_fwd_kernel(const float
   const int g = lane / LPR, c4 = lane % LPR;
   const float4* __restrict__ E4 = reinterpret_cast<const float4*>(Ej) + c4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int n0 = 0; n0 < k; n0 += RPI) {
-    const int nn = n0 + g;
-    const int jj = __shfl(j, nn & (kWave - 1));
-    const float aa = __shfl(a, nn & (kWave - 1));
-    if (nn < k && jj != 0) {
-      const float4 x = E4[static_cast<int64_t>(jj - 1) * LPR];
-      acc.x = fmaf(aa, x.x, acc.x); acc.y = fmaf(aa, x.y, acc.y); acc.z = fmaf(aa, x.z, acc.z); acc.w = fmaf(aa, x.w, acc.w);
+  for (int n1 = 0; n1 < k; n1 += 4 * RPI) {            // four gather instructions in flight
+    float4 x[4];
+    float aa[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int nn = n1 + u * RPI + g;
+      const int jj = __shfl(j, nn & (kWave - 1));
+      const float av = __shfl(a, nn & (kWave - 1));
+      const bool ok = nn < k && jj != 0;
+      aa[u] = ok ? av : 0.f;
+      x[u] = ok ? E4[static_cast<int64_t>(jj - 1) * LPR] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc.x = fmaf(aa[u], x[u].x, acc.x); acc.y = fmaf(aa[u], x[u].y, acc.y);
+      acc.z = fmaf(aa[u], x[u].z, acc.z); acc.w = fmaf(aa[u], x[u].w, acc.w);
     }
   }
 #pragma unroll

@@ -64,3 +64,15 @@ def row_add_at(dst, pos, src):
     _lib.check(_lib.load().tagrec_row_add_at_f32(_lib.ptr(dst), _lib.ptr(pos), _lib.ptr(src), src.shape[0], src.shape[1],
                                                  _lib.stream_ptr()), "row_add_at")
     return dst
+
+
+def masked_colsum(d_out, out):
+    """column sums of d_out * (out > 0): the bias gradient of a ReLU layer."""
+    lib = _lib.load()
+    n, D = d_out.shape
+    res = torch.empty(D, dtype=torch.float32, device=d_out.device)
+    ws_n = lib.tagrec_masked_colsum_workspace(D)
+    ws = torch.empty(ws_n, dtype=torch.float32, device=d_out.device)
+    _lib.check(lib.tagrec_masked_colsum_f32(_lib.ptr(d_out), _lib.ptr(out), n, D, _lib.ptr(res), _lib.ptr(ws), ws_n, _lib.stream_ptr()),
+               "masked_colsum")
+    return res

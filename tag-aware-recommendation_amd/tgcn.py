@@ -354,7 +354,8 @@ class _FusedDense(torch.autograd.Function):
                           _lib.stream_ptr()), "tgcn_fuse_bwd")
         dwb, dq, dp = small[:3 * C].reshape(C, 3), small[3 * C:3 * C + A], small[3 * C + A:3 * C + 2 * A]
         # every gradient that is a product over the node axis: dWf, G (-> dw1, dw2, dw3) and dU, one launch
-        dbf = (d_out * (out > 0)).sum(0)
+        from . import proj as PJ
+        dbf = PJ.masked_colsum(d_out, out) if 256 % (Dout // 4) == 0 else (d_out * (out > 0)).sum(0)
         res_n = lib.tagrec_tgcn_fuse_wf_result(D, Dout)
         res = torch.empty(res_n, dtype=torch.float32, device=dev)
         wf_n = lib.tagrec_tgcn_fuse_wf_workspace(D, Dout)

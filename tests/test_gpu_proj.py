@@ -105,6 +105,18 @@ def test_small_mm_and_row_add_at():
     assert torch.equal(dst, want)
 
 
+def test_masked_colsum():
+    gen = torch.Generator().manual_seed(4)
+    for n, D in ((100_003, 128), (7, 64), (0, 32), (5000, 16)):
+        d, o = _rnd(gen, n, D), _rnd(gen, n, D)
+        want = (d.double() * (o > 0)).sum(0)
+        got = PJ.masked_colsum(d, o)
+        if n == 0:
+            assert float(got.abs().max()) == 0.0
+        else:
+            _close(got, want, 2e-5)
+
+
 def test_shape_checks_fail_loudly():
     X, W = torch.zeros(8, 24, device=DEV), torch.zeros(24, 32, device=DEV)
     with pytest.raises(T.TagrecError, match="16, 32, 64 or 128"):
