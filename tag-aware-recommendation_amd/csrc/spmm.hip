@@ -563,36 +563,87 @@ __device__ __forceinline__ float4 gather_pairs_da(const GraphView& g, const int3
   return acc;
 }
 
+// Short rows, 64 / LPR of them per wavefront: lane group q walks ITS OWN row (row = wave * NPI + q), so the fixed cost of a
+// row -- row pointer -> entries -> gather -> store, three dependent memory latencies that a destination with ~6 incoming
+// pairs cannot amortise -- is paid once per NPI rows, and the dot product of entry e is kept by lane e of the group without a
+// shuffle.  Long rows: one chunk per wave as in spmm_rows_kernel (the first blocks), folded by spmm_finish_kernel.
 template <int LPR, int EPI>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void attn_pull_da_kernel(GraphView g, const int32_t* __restrict__ pair,
                                                                                const float* __restrict__ dOut,
                                                                                const float* __restrict__ Ej, float* __restrict__ da,
                                                                                EpiArgs e, LongView lv) {
+  constexpr int NPI = kWave / LPR;
   const int lane = threadIdx.x & (kWave - 1);
-  int64_t r, start, end;
-  int64_t chunk = -1;
   if (blockIdx.x < lv.chunk_blocks) {
-    chunk = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t chunk = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (chunk >= lv.n_chunks) return;
     const int2 d = lv.chunk_desc[chunk];
-    r = lv.long_rows[d.x];
-    start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
+    const int64_t r = lv.long_rows[d.x];
+    const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
-    end = (start + kChunk < row_end) ? start + kChunk : row_end;
-  } else {
-    r = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
-    if (r >= g.n_rows) return;
-    start = g.rowptr[r];
-    end = g.rowptr[r + 1];
-    if (end - start > kLongRow) return;
-  }
-  const float4 own = start < end ? reinterpret_cast<const float4*>(Ej)[r * LPR + (lane % LPR)] : f4_zero();
-  const float4 acc = gather_pairs_da<LPR>(g, pair, start, end, lane, dOut, own, da);
-  if (chunk >= 0) {
+    const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
+    const float4 own = reinterpret_cast<const float4*>(Ej)[r * LPR + (lane % LPR)];
+    const float4 acc = gather_pairs_da<LPR>(g, pair, start, end, lane, dOut, own, da);
     if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[chunk * LPR + lane] = acc;
     return;
   }
-  row_epilogue<LPR, EPI>(acc, r, lane, e);
+  const int q = lane / LPR, c = lane % LPR;
+  const int64_t wv = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t r = wv * NPI + q;
+  const bool valid = r < g.n_rows;
+  int64_t start = 0;
+  int len = 0;
+  bool is_long = false;
+  if (valid) {
+    start = g.rowptr[r];
+    const int64_t deg = g.rowptr[r + 1] - start;
+    is_long = deg > kLongRow;
+    len = is_long ? 0 : static_cast<int>(deg);
+  }
+  int maxlen = len;
+#pragma unroll
+  for (int m = LPR; m < kWave; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+  const float4 own = len > 0 ? reinterpret_cast<const float4*>(Ej)[r * LPR + c] : f4_zero();
+  const float4* __restrict__ Xv = reinterpret_cast<const float4*>(dOut) + c;
+  float4 acc = f4_zero();
+  for (int base = 0; base < maxlen; base += LPR) {
+    const int n = len - base;                           // entries of this group's row in the batch (may be <= 0)
+    int my_src = 0, my_pair = 0;
+    float my_val = 0.f, my_da = 0.f;
+    if (c < n) {
+      my_src = ld_stream(g.col + start + base + c);
+      my_val = ld_stream(g.val + start + base + c);
+      my_pair = ld_stream(pair + start + base + c);
+    }
+    const int nmax = (maxlen - base) < LPR ? (maxlen - base) : LPR;
+    for (int i = 0; i < nmax; i += 4) {
+      float4 x[4];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int en = i + u;
+        const int src = __shfl(my_src, q * LPR + (en & (LPR - 1)));
+        const float w = __shfl(my_val, q * LPR + (en & (LPR - 1)));
+        const bool ok = en < n;
+        v[u] = ok ? w : 0.f;
+        x[u] = ok ? Xv[static_cast<int64_t>(src) * LPR] : f4_zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f4_fma(acc, v[u], x[u]);
+        const float d = group_sum_dpp<LPR>(f4_dot(x[u], own));
+        if (c == i + u) my_da = d;                      // lane e of the group keeps entry e's dot product
+      }
+    }
+    if (c < n) da[my_pair] = my_da;
+  }
+  if (!valid || is_long) return;
+  const int64_t off = r * LPR + c;
+  if constexpr (EPI == EPI_AXPY) {
+    const float4 b = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
+    acc = make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y), fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w));
+  }
+  st_stream(reinterpret_cast<float4*>(e.Y) + off, acc);
 }
 
 // A lanes per pair, 64 / A pairs per step; on return lanes [0, A/4) hold the row's float4 columns of v (.) sum
@@ -1194,7 +1245,8 @@ int launch_pull_da(const tagrec_graph* g, const int32_t* pair, const float* dOut
                    hipStream_t s) {
   const GraphView gv{g->n_rows, g->rowptr, g->col, g->val, g->n_cols};
   const int threads = kWavesPerBlock * kWave;
-  const unsigned blocks = static_cast<unsigned>((g->n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  constexpr int rows_per_block = kWavesPerBlock * (kWave / LPR);          // every lane group of a wave walks its own row
+  const unsigned blocks = static_cast<unsigned>((g->n_rows + rows_per_block - 1) / rows_per_block);
   LongView lv{g->long_rows, g->chunk_desc, g->n_chunks, nullptr, 0};
   if (g->n_long > 0) {
     int rc = ensure_slab(g, LPR * 4);
