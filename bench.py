@@ -71,6 +71,10 @@ def parse():
                          "ranks), feature = columns (default up to 4 ranks when dim / ranks >= 16); both = time the two "
                          "partitions one after the other in the same job: the line is the one `auto` picks, the other is "
                          "printed under extra.partitions")
+    ap.add_argument("--all-gather", choices=["collective", "direct"], default="collective",
+                    help="row sharding: how a row block reaches the other ranks -- collective = all_gather_into_tensor (RCCL's "
+                         "schedule for the communicator), direct = one grouped send / receive pair per peer (every GPU pushes its "
+                         "block over the xGMI link it shares with each peer, SURVEY.md 8e); extra.collectives.probe times both")
     ap.add_argument("--chunks", type=int, default=0, help="row blocks per shard for the pipelined all-gathers (0 = default)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 and the ranks exchange "
@@ -322,11 +326,13 @@ def bench_tgcn(args, ceilings=None):
                            "of convolution output per layer)",
            "extra": {"build_s": round(t_build, 1), "last_loss": [float(x.detach()) for x in last],
                      "transtag_step_ms": t_tt * 1e3,
-                     "attention_ms_per_step": (sum(ms.get("attn_fwd", [])) + sum(ms.get("attn_bwd", []))) / K,
+                     "attention_ms_per_step": sum(sum(v) for kk, v in ms.items() if kk.startswith("attn")) / K,
                      "pruned_forward": bool(model.prune_forward),
                      "fused_dense_ms_per_step": sum(sum(ms.get(kk, [])) for kk in ("fuse_fwd", "fuse_bwd", "fuse_wf")) / K,
-                     "note": "type attention + convolutions + fusion layer = fused MFMA kernels (csrc/tgcn_fuse.hip: fwd, bwd-data, "
-                             "bwd-Wf); neighbour attention = csrc/tgcn.hip; the CPU reference cannot materialise this size"}}
+                     "note": "the step is one hand-derived autograd node (tgcn_step.py): fused MFMA dense block (csrc/tgcn_fuse.hip: fwd, "
+                             "bwd-data, bwd-Wf; the three node types of a layer in one launch), neighbour attention (csrc/tgcn.hip) with the "
+                             "backward pulled over on-the-spot inverted tables (csrc/spmm.hip attn_pull_*), projections on csrc/proj.hip; "
+                             "no library GEMM in the step; the CPU reference cannot materialise this size"}}
     del model, opt, prod, ds
     torch.cuda.empty_cache()
     return out
@@ -357,25 +363,46 @@ def launch_ranks(args):
     return rc
 
 
-def collective_probe(shape, dev, world, reps=5):
-    """ms of one all_gather_into_tensor of a [rows, D] block per rank and of one all_reduce of a [3, 1536, D] buffer
-    (the two exchange shapes of the row-sharded step), measured before the timed region."""
+def collective_probe(shape, dev, world, rank, reps=5):
+    """ms and achieved GB/s (bytes received per rank / time) of one exchange of a [rows, D] block per rank, by the collective
+    (all_gather_into_tensor) and by the direct schedule (one grouped send / receive pair per peer), and ms of one
+    all_reduce of a [3, 1536, D] buffer -- the exchange shapes of the row-sharded step, measured before the timed region.
+    On the xGMI full mesh a direct exchange is bounded by ONE link per peer (~64 GB/s per direction each, all in parallel: rows
+    * D * 4 B / 64 GB/s), a ring by (G - 1) hops over one link: the two GB/s figures tell which one ran."""
     import torch.distributed as dist
     rows, D = shape
     x = torch.zeros(rows, D, device=dev)
     full = torch.empty(rows * world, D, device=dev)
     small = torch.zeros(3, 1536, D, device=dev)
+
+    def direct():
+        ops = []
+        for d in range(1, world):
+            to, frm = (rank + d) % world, (rank - d) % world
+            ops.append(dist.P2POp(dist.isend, x, to))
+            ops.append(dist.P2POp(dist.irecv, full[frm * rows:(frm + 1) * rows], frm))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
     out = {}
-    for name, fn in (("all_gather_block_ms", lambda: dist.all_gather_into_tensor(full, x)),
-                     ("all_reduce_batch_rows_ms", lambda: dist.all_reduce(small))):
+    nbytes = rows * D * 4 * (world - 1)
+    for name, fn in (("all_gather_block_collective", lambda: dist.all_gather_into_tensor(full, x)),
+                     ("all_gather_block_direct", direct),
+                     ("all_reduce_batch_rows", lambda: dist.all_reduce(small))):
         fn()
+        torch.cuda.synchronize()
+        dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(reps):
             fn()
         torch.cuda.synchronize()
-        out[name] = (time.perf_counter() - t) / reps * 1e3
-    out["all_gather_block_bytes_in"] = rows * D * 4 * (world - 1)
+        ms = (time.perf_counter() - t) / reps * 1e3
+        out[name + "_ms"] = ms
+        if name.startswith("all_gather"):
+            out[name + "_GBs_in"] = nbytes / (ms * 1e-3) / 1e9
+    out["all_gather_block_bytes_in"] = nbytes
+    out["one_link_bound_ms_at_64GBs"] = rows * D * 4 / 64e9 * 1e3
     return out
 
 
@@ -391,7 +418,8 @@ def run_table_model(args, dev, rank, world, sharded, ceilings=None, ds=None, lig
     nu = ni = max(int(1_000_000 * args.scale), 2000)
     ne = max(int(50_000_000 * args.scale), 40000)
     D, L, B = args.dim, args.layers, args.batch
-    cfg = T.get_config(args.model, use_tag=False, dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B)
+    cfg = T.get_config(args.model, use_tag=False, dim_latent=D, dim_layer_list=[D] * L, device=dev, train_batch=B,
+                       all_gather=args.all_gather)
     parallel = args.parallel
     if parallel == "auto":
         # Byte budget of DESIGN.md section 6: the row partition (the reference's folds) sends 4 table shards per step over
@@ -501,7 +529,7 @@ def run_table_model(args, dev, rank, world, sharded, ceilings=None, ds=None, lig
     gc.collect()
     gc.freeze()
     row_sharded = sharded and parallel == "row"
-    probe = collective_probe((model.part.rc, D), dev, world) if (row_sharded and world > 1) else None
+    probe = collective_probe((model.part.rc, D), dev, world, rank) if (row_sharded and world > 1) else None
     # per-kernel HIP events on the launch stream; a row shard is walked in row blocks, one handle (and event list) each
     timed_graphs = model.graph_chunks if row_sharded else [timed_graph]
     for g_ in timed_graphs:
@@ -519,6 +547,7 @@ def run_table_model(args, dev, rank, world, sharded, ceilings=None, ds=None, lig
         waits = model.timing_ms()
         model.timing = None
         comm = {"world_size_seen_by_torch_distributed": dist.get_world_size(), "backend": dist.get_backend(),
+                "all_gather": getattr(model, "all_gather_mode", None),
                 "row_blocks_per_shard": model.part.n_chunks if row_sharded else None,
                 "rows_per_rank": model.part.per if row_sharded else n,
                 "columns_per_rank": D if row_sharded else Dl,

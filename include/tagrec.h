@@ -420,6 +420,11 @@ int tagrec_tgcn_attn_bwd_ds_f32(const float* P, const float* Q, const float* WT,
 int tagrec_attn_pull_dq_f32(const tagrec_graph* inv, const float* comp, const float* v, int A, const float* B, float* dQ,
                             void* stream);
 int tagrec_attn_keys_i32(const int32_t* idx, int64_t n, int32_t n_dst, int32_t* key, void* stream);
+/*   tagrec_nbr_gather_i32 : the neighbour tables of a ROW SUBSET in compact numbering (tgcn.py:194-202 restricted to the rows a
+ *   mini-batch needs): out_idx[i, :] = pos[idx[rows[i], :]] (pos NULL: ids unchanged; pos[0] = 0 keeps the pad),
+ *   out_widx[i, :] = widx[rows[i], :]. */
+int tagrec_nbr_gather_i32(const int32_t* idx, const int32_t* widx, const int64_t* rows, const int32_t* pos, int64_t n_rows,
+                          int k, int32_t* out_idx, int32_t* out_widx, void* stream);
 /*     tagrec_attn_seg_dq_f32 : the same dQ from the pair list SORTED by destination (dest_sorted = the sorted keys, entries
  *                               with dest >= n_dst are the pads at the tail), as a balanced segmented sum: 256 entries per
  *                               wavefront, a finished segment ADDED to dQ by float atomics (the caller zeroes dQ; two relations

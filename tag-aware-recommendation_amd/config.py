@@ -17,6 +17,7 @@ _BASE = {
     "message_drop_list": [0.0, 0.0, 0.0], "node_drop": 0.0,
     "seed": 2020, "cpu_core": 4, "split_adj_k": 1,
     "hip_graph": False,       # Basic_train: replay each phase's step as one captured HIP graph (train.GraphedStep)
+    "all_gather": "collective",   # row-sharded models (dist.py): "direct" = one grouped send / receive pair per peer
 }
 
 # utility/config.py:1-12, 41-52

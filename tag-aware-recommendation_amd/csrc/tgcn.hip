@@ -383,6 +383,22 @@ __global__ __launch_bounds__(256) void attn_invert_fill_kernel(const int64_t* __
   }
 }
 
+// neighbour / weight ids of a row subset in compact numbering: out[i, :] = pos[idx[rows[i], :]] (pos == nullptr: ids as they
+// are; 0 stays the pad), wout[i, :] = widx[rows[i], :] -- one pass instead of two index_selects and a look-up per relation
+__global__ __launch_bounds__(256) void nbr_gather_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ widx,
+                                                          const int64_t* __restrict__ rows, const int32_t* __restrict__ pos,
+                                                          int64_t n_rows, int k, int32_t* __restrict__ out, int32_t* __restrict__ wout) {
+  const int64_t total = n_rows * k;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += stride) {
+    const int64_t i = e / k;
+    const int64_t srcpos = rows[i] * k + (e - i * k);
+    const int32_t j = idx[srcpos];
+    out[e] = pos ? pos[j] : j;
+    wout[e] = widx[srcpos];
+  }
+}
+
 // sort keys of an on-the-spot table inversion: destination row of every (node, slot) pair, pads behind the last row
 __global__ __launch_bounds__(256) void attn_keys_kernel(const int32_t* __restrict__ idx, int64_t n, int32_t n_dst, int32_t* __restrict__ key) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
@@ -556,6 +572,19 @@ extern "C" int tagrec_attn_invert_fill(const int64_t* order, const float* attn, 
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   attn_invert_fill_kernel<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(order, attn, k, n, pair, src, val);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_nbr_gather_i32(const int32_t* idx, const int32_t* widx, const int64_t* rows, const int32_t* pos, int64_t n_rows,
+                                     int k, int32_t* out_idx, int32_t* out_widx, void* stream) {
+  TAGREC_REQUIRE(n_rows >= 0 && k >= 1, "nbr_gather: bad shape");
+  if (n_rows == 0) return TAGREC_OK;
+  TAGREC_REQUIRE(idx && widx && rows && out_idx && out_widx, "nbr_gather: null pointer");
+  int64_t blocks = (n_rows * k + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  nbr_gather_kernel<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(idx, widx, rows, pos, n_rows, k, out_idx,
+                                                                                                  out_widx);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

@@ -29,6 +29,18 @@ constexpr int kBitC = 32;      // num_bit_conv  (utility/config.py:44)
 constexpr int kVecC = 8;       // num_vec_conv  (utility/config.py:45)
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+// sum over the 16 lanes of a DPP row (= the 16 nodes of a lane row q) at register speed: __shfl_xor compiles to
+// ds_bpermute_b32 -- an LDS round trip and two address instructions per step
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);      // row_half_mirror
+  return dpp_add<0x140>(v);   // row_mirror
+}
 __device__ __forceinline__ float quad_sum(float v) {   // over the 4 lanes that share a node (q = 0..3)
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
@@ -723,8 +735,8 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
 #pragma unroll
   for (int i = 0; i < AS; ++i) {
     float a = q_acc[i], b = p_acc[i];
-    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
-    b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4); b += __shfl_xor(b, 8);
+    a = row16_sum(a);
+    b = row16_sum(b);
     if (r == 0) { atomicAdd(&sh_q[q * AS + i], a); atomicAdd(&sh_p[q * AS + i], b); }
   }
   __syncthreads();
@@ -908,8 +920,7 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
         // over the 16 nodes of a lane row by DPP (register speed); the four rows add into their own LDS slots without a
         // return value (the two cross-row shuffle rounds went through the LDS pipe and stalled the wave once per filter;
         // four lanes adding into ONE address serialise and cost more than they save)
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+        a0 = row16_sum(a0); a1 = row16_sum(a1); a2 = row16_sum(a2);
         if (r == 0) {
           atomicAdd(&sh_wb4[(c * 3) * 4 + q], a0); atomicAdd(&sh_wb4[(c * 3 + 1) * 4 + q], a1); atomicAdd(&sh_wb4[(c * 3 + 2) * 4 + q], a2);
         }
@@ -1018,8 +1029,8 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
 #pragma unroll
   for (int i = 0; i < AS; ++i) {
     float a = q_acc[i], b = p_acc[i];
-    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
-    b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4); b += __shfl_xor(b, 8);
+    a = row16_sum(a);
+    b = row16_sum(b);
     if (r == 0) { atomicAdd(&sh_q[q * AS + i], a); atomicAdd(&sh_p[q * AS + i], b); }
   }
   __syncthreads();

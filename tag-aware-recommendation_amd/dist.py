@@ -223,6 +223,15 @@ class HipOps:
 # Tests set this to run every collective through torch.distributed even in a group of ONE rank (where the models would
 # otherwise copy): the RCCL calls -- dtypes, contiguity, async handles, stream ordering -- then run on a one-GPU box.
 ALWAYS_COLLECTIVE = False
+# How a block of a row shard reaches the other ranks (`_Gather.put`):
+#   "collective": dist.all_gather_into_tensor -- whatever schedule RCCL picks for the communicator (a ring moves every shard
+#                 over every link in turn: G - 1 hops per exchange);
+#   "direct":     one send to and one receive from EVERY peer, posted together (dist.batch_isend_irecv = one grouped
+#                 ncclSend / ncclRecv launch) -- the schedule SURVEY.md 8e prescribes for the xGMI full mesh: each GPU pushes
+#                 its block straight over the link it shares with each peer, all G - 1 links at once, one hop.
+# Same bytes, same destination layout, bit-identical result (a copy); selectable per model (config["all_gather"]) and from
+# bench.py (--all-gather), default "collective".
+ALL_GATHER_MODES = ("collective", "direct")
 
 
 def shard_rows(n, world, n_chunks=1):
@@ -290,6 +299,10 @@ def transpose_csr(rowptr, col, val, n_cols):
     return rp, (key - trow * n_rows).to(torch.int32), val[order].contiguous()
 
 
+def _global_rank(group, r):
+    return r if group is None else dist.get_global_rank(group, r)
+
+
 class _Gather:
     """One table being all-gathered block by block.  `put(c, x_block)` starts the all-gather of block c (asynchronous:
     with RCCL it runs on the process group's stream behind an event of the producing stream, so the next block's
@@ -301,6 +314,7 @@ class _Gather:
         shape = (m.part.n_pad,) if width is None else (m.part.n_pad, width)
         self.full = m._scratch((key, width, dtype), shape, dtype)
         self.works = []
+        self.keep = []
 
     def put(self, c, block):
         m = self.m
@@ -309,7 +323,20 @@ class _Gather:
             dst.copy_(block)
             return
         m.comm_bytes += block.numel() * block.element_size() * (m.world - 1)
-        self.works.append(dist.all_gather_into_tensor(dst, block.contiguous(), group=m.group, async_op=True))
+        block = block.contiguous()
+        if getattr(m, "all_gather_mode", "collective") == "direct":
+            rows = block.shape[0]
+            dst[m.rank * rows:(m.rank + 1) * rows].copy_(block)                     # own slot: a local copy
+            ops = []
+            for d in range(1, m.world):                                                # peer order staggered by rank
+                to, frm = (m.rank + d) % m.world, (m.rank - d) % m.world
+                ops.append(dist.P2POp(dist.isend, block, _global_rank(m.group, to), group=m.group))
+                ops.append(dist.P2POp(dist.irecv, dst[frm * rows:(frm + 1) * rows], _global_rank(m.group, frm), group=m.group))
+            if ops:
+                self.works.extend(dist.batch_isend_irecv(ops))
+                self.keep.append(block)            # the send buffer must outlive the transfer
+            return
+        self.works.append(dist.all_gather_into_tensor(dst, block, group=m.group, async_op=True))
 
     def put_all(self, x):
         for c in range(self.m.part.n_chunks):
@@ -320,7 +347,7 @@ class _Gather:
         ev = self.m._wait_begin()
         for w in self.works:
             w.wait()
-        self.works = []
+        self.works, self.keep = [], []
         self.m._wait_end(ev, "all_gather_wait")
         return self.full
 
@@ -353,7 +380,13 @@ class _ShardedLoss(torch.autograd.Function):
             mid_mask.index_fill_(0, loc, 1)
         n_pull = L - 1 if restricted else L               # layers computed as pull products on (a subset of) the local rows
         x = x0
-        gat = _Gather(m, D, key="fwd").put_all(x0) if n_pull > 0 else None
+        gat = None
+        if n_pull > 0:
+            gat, m._x0_prefetched = m._x0_prefetched, None       # started by the previous step's fused last hop, if any
+            if gat is None:
+                gat = _Gather(m, D, key="fwd").put_all(x0)
+        elif m._x0_prefetched is not None:
+            m.invalidate_prefetch()
         for k in range(n_pull):
             masked = restricted and k == L - 2
             xf = gat.table()
@@ -467,10 +500,17 @@ class _ShardedLoss(torch.autograd.Function):
             fused = fused_optimizer(m) if (restricted and m.reg == 0 and dzf is not None) else None
             if fused is not None:          # Adam in the epilogue of the last hop (Adam.fuse_into): no gradient tensor
                 am, av, step = fused.fused_state(m.table)
+                # the updated rows of block c are the first thing the NEXT step exchanges (the all-gather of X^0 in front of
+                # its first layer): start that exchange now, behind block c's update, so it runs under the remaining blocks
+                # of this hop and everything up to the next forward pass (one of the step's four table exchanges hidden)
+                pre = _Gather(m, m.table.shape[1], key="fwd") if m.prefetch_x0 and L >= 2 else None
                 for c in range(part.n_chunks):
                     r = part.chunk_rows(c)
                     ops.last_hop_adam(m.graph_chunks[c], operand[0], operand[1], operand[2], d_out[r], s, dzf[r],
                                       m.table.data[r], am[r], av[r], fused.lr, fused.betas, fused.eps, step)
+                    if pre is not None:
+                        pre.put(c, m.table.data[r])
+                m._x0_prefetched = pre
                 fused.fused_commit(m.table)
                 ctx.raws = ctx.invs = ctx.y_top = None
                 return None, None, None
@@ -529,6 +569,9 @@ class ShardedLightGCN(torch.nn.Module):
         self.reg = config["reg"]
         self.loss_func = config["mul_loss_func"]
         self.restrict_forward = bool(config.get("restrict_forward", True))
+        self.all_gather_mode = config.get("all_gather", "collective")
+        if self.all_gather_mode not in ALL_GATHER_MODES:
+            raise _lib.TagrecError(f"config['all_gather'] must be one of {ALL_GATHER_MODES}, got {self.all_gather_mode!r}")
         if symmetric is None:
             symmetric = config.get("norm_type", "bi_norm") in ("bi_norm", "plain")
         if not symmetric:
@@ -563,6 +606,22 @@ class ShardedLightGCN(torch.nn.Module):
         self._buffers_cache = {}
         self.timing = None
         self.comm_bytes = 0
+        # the all-gather of X^0 for the next step, started by a fused last hop (see _ShardedLoss.backward).  It is consumed
+        # by the next loss(); anything else that may change or re-gather the table drops it (train / eval switches,
+        # forward(), load_state_dict, invalidate_prefetch()).  config["prefetch_x0"] = False switches it off.
+        self.prefetch_x0 = bool(config.get("prefetch_x0", True))
+        self._x0_prefetched = None
+        self._register_load_state_dict_pre_hook(lambda *a, **k: self.invalidate_prefetch())
+
+    def invalidate_prefetch(self):
+        """Call after changing `table` by hand between two steps: the next step gathers X^0 afresh."""
+        if self._x0_prefetched is not None:
+            self._x0_prefetched.table()              # drain the exchange in flight before its buffer is reused
+            self._x0_prefetched = None
+
+    def train(self, mode=True):
+        self.invalidate_prefetch()
+        return super().train(mode)
 
     # -- scratch: gathered tables are reused from step to step (no 512 MB allocations inside the step) -------------
     def _scratch(self, key, shape, dtype, zero=False):
@@ -631,6 +690,7 @@ class ShardedLightGCN(torch.nn.Module):
     def forward(self):
         """Full propagated tables, gathered on every rank (evaluation path): every layer on all rows."""
         L, s = self.num_layer, 1.0 / (self.num_layer + 1)
+        self.invalidate_prefetch()
         x0 = self.table.detach()
         out = x0 * s
         x = x0
@@ -927,6 +987,9 @@ class ShardedNGCF(torch.nn.Module):
         crp, cc, cv = transpose_csr(trp, tc, tv, self.n_pad)
         self.graph_cols = self.ops.row_block(crp, cc, cv, 0, self.n_pad, self.per)
         self.restrict_forward = bool(config.get("restrict_forward", True))
+        self.all_gather_mode = config.get("all_gather", "collective")
+        if self.all_gather_mode not in ALL_GATHER_MODES:
+            raise _lib.TagrecError(f"config['all_gather'] must be one of {ALL_GATHER_MODES}, got {self.all_gather_mode!r}")
         num_list = [self.n_user, self.n_item] + ([data.num["tag"]] if config["use_tag"] else [])
         assert sum(num_list) == self.n_nodes
         full = xavier_tables(num_list, self.dims[0], "cpu")            # same seed on every rank -> same table, same W / b
@@ -1187,6 +1250,9 @@ class FeatureShardedLightGCN(torch.nn.Module):
         self.reg = config["reg"]
         self.loss_func = config["mul_loss_func"]
         self.restrict_forward = bool(config.get("restrict_forward", True))
+        self.all_gather_mode = config.get("all_gather", "collective")
+        if self.all_gather_mode not in ALL_GATHER_MODES:
+            raise _lib.TagrecError(f"config['all_gather'] must be one of {ALL_GATHER_MODES}, got {self.all_gather_mode!r}")
         if config.get("norm_type", "bi_norm") not in ("bi_norm", "plain"):
             raise _lib.TagrecError(
                 f"FeatureShardedLightGCN: norm_type {config.get('norm_type')!r} is not symmetric; the backward products use "

@@ -230,10 +230,18 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
             rows = rows_out[src]
             if m[src] == 0:
                 continue
-            idx = model.nbr[r][0] if rows is None else model.nbr[r][0].index_select(0, rows)
-            widx = model.nbr[r][1] if rows is None else model.nbr[r][1].index_select(0, rows)
-            if rows_in[nb] is not None:                      # neighbour ids -> positions in the compact table
+            if rows is None and rows_in[nb] is None:
+                idx, widx = model.nbr[r]
+            elif rows is None:                               # neighbour ids -> positions in the compact table
+                idx, widx = model.nbr[r][0], model.nbr[r][1]
                 idx = pos_in[nb].index_select(0, idx.flatten().long()).reshape(idx.shape)
+            else:                                            # the rows' slices of both tables, renumbered, in one pass
+                kk = model.nbr[r][0].shape[1]
+                idx = torch.empty(m[src], kk, dtype=torch.int32, device=dev)
+                widx = torch.empty(m[src], kk, dtype=torch.int32, device=dev)
+                _lib.check(lib.tagrec_nbr_gather_i32(_lib.ptr(model.nbr[r][0]), _lib.ptr(model.nbr[r][1]), _lib.ptr(rows),
+                                                     _lib.ptr(pos_in[nb] if rows_in[nb] is not None else None), m[src], kk,
+                                                     _lib.ptr(idx), _lib.ptr(widx), _lib.stream_ptr()), "nbr_gather")
             _, attns[r] = attn_fwd(P[(src, nb)], Q[nb], WT[nb], att[nb][3].reshape(-1), X[nb], idx, widx,
                                    out=T3[SLOT[nb]][rng[src]])
             idxs[r] = (idx, widx)

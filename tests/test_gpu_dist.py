@@ -40,8 +40,12 @@ def _worker(rank, world, port, out_dir, kind, fixture="lightgcn_toy", backend="g
     try:
         fx = load_golden(fixture)
         csr = oadj.normalise(oadj.block_adjacency(*blocks_from_fixture(fx, 1)), "bi_norm")
+        direct = kind.endswith("_direct")         # blocks travel by one send / receive pair per peer instead of the collective
+        out_name = kind
+        if direct:
+            kind = kind[:-len("_direct")]
         cfg = T.get_config("lightgcn", use_tag=True, dim_layer_list=[int(x) for x in fx["layers"]], dim_latent=int(fx["D"]),
-                           reg=float(fx["reg"]), device=dev)
+                           reg=float(fx["reg"]), device=dev, all_gather="direct" if direct else "collective")
         ds = T.synth.Dataset()
         ds.num = {"user": int(fx["n_user"]), "item": int(fx["n_item"]), "tag": int(fx["n_tag"])}
         args = (ds, cfg, torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.col).to(dev), torch.from_numpy(csr.val).to(dev),
@@ -72,13 +76,14 @@ def _worker(rank, world, port, out_dir, kind, fixture="lightgcn_toy", backend="g
             opt.step()
         table = m.gathered_table()
         if rank == 0:
-            np.savez(os.path.join(out_dir, f"{kind}.npz"), losses=np.array(losses), table=table.cpu().numpy()[:full.shape[0]])
+            np.savez(os.path.join(out_dir, f"{out_name}.npz"), losses=np.array(losses), table=table.cpu().numpy()[:full.shape[0]])
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("kind,fixture", [("feature", "lightgcn_toy"), ("row", "lightgcn_toy"), ("row_restricted", "lightgcn_toy"),
                                           ("row_restricted", "lightgcn_toy_d256"), ("row", "lightgcn_toy_d256"),
+                                          ("row_restricted_direct", "lightgcn_toy_d256"), ("row_direct", "lightgcn_toy"),
                                           ("feature", "lightgcn_toy_d256"), ("feature_restricted", "lightgcn_toy"),
                                           ("feature_restricted", "lightgcn_toy_d256")])
 def test_two_ranks_real_kernels(tmp_path, golden, kind, fixture):
