@@ -376,6 +376,8 @@ def collective_probe(shape, dev, world, rank, reps=5):
     small = torch.zeros(3, 1536, D, device=dev)
 
     def direct():
+        if dist.get_backend() != "nccl":
+            torch.cuda.synchronize()               # (gloo rehearsal: its point-to-point path does not look at HIP streams)
         ops = []
         for d in range(1, world):
             to, frm = (rank + d) % world, (rank - d) % world
@@ -577,6 +579,38 @@ def run_table_model(args, dev, rank, world, sharded, ceilings=None, ds=None, lig
         dtb, _ = timed(bb[1:])
         extra[f"triplets_per_s_at_B{BB}"] = 2 * BB / dtb
         extra[f"ms_per_step_at_B{BB}"] = dtb / 2 * 1e3
+
+    if args.model in ("lightgcn", "ngcf") and not sharded and not light and not routed:
+        # the SAME step replayed as one captured HIP graph (train.GraphedStep): the optimizer's step counter and factors live
+        # in device memory (Adam(capturable=True)), the table's update stays inside the last backward product
+        try:
+            opt_g = T.Adam(model.parameters(), lr=cfg["lr"], capturable=True)
+            if not args.no_fused_adam:
+                opt_g.fuse_into(model)
+            for b in batches[:2]:                      # eager: optimizer state and every lazily sized buffer exist before capture
+                lossx = model.loss(b)
+                opt_g.zero_grad()
+                sum(lossx).backward()
+                opt_g.step()
+            gstep = T.GraphedStep(model.loss, opt_g, batches[0])
+            for b in batches[:W]:
+                gstep(b)
+            barrier()
+            t = time.perf_counter()
+            for b in batches[W:]:
+                gstep(b)
+            barrier()
+            dtg = time.perf_counter() - t
+            extra["hip_graph_replay"] = {"ms_per_step": dtg / K * 1e3, "eager_ms_per_step": dt / K * 1e3,
+                                         "fused_adam": bool(not args.no_fused_adam),
+                                         "step_workspace_MB": round(model.step_ws.nbytes() / 2 ** 20, 1)
+                                         if getattr(model, "step_ws", None) is not None else None}
+            del gstep
+            if not args.no_fused_adam:
+                opt.fuse_into(model)                   # hand the table back to the eager optimizer
+        except Exception as exc:                       # capture is an extra: the headline above stands without it
+            extra["hip_graph_replay"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.synchronize()
 
     # roofline of the dominant kernel: fused forward layer (local rows of this rank)
     dom = "spmm_norm_acc" if args.model == "lightgcn" else "spmm"

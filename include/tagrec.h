@@ -323,6 +323,15 @@ int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* v, int64_t 
 int tagrec_spmm_axpy_adam_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags, const unsigned* in_count,
                               const float* B, float b_scale, const uint8_t* b_flags, float* p, float* m, float* v,
                               float lr, float b1, float b2, float eps, int64_t step, int D, void* stream);
+/* The same with the optimizer's step counter (int64) and its two step-dependent factors ([lr / (1 - b1^t), sqrt(1 - b2^t)])
+ * in DEVICE memory: tagrec_adam_advance moves them one step forward on the stream (a one-thread kernel); the product reads
+ * the factors there.  Nothing step-dependent is baked into the launch, so a captured HIP graph of the whole training step
+ * (loss, backward, optimizer) replays correctly (train.GraphedStep with Adam(capturable=True).fuse_into(model)). */
+int tagrec_adam_advance(int64_t* step_dev, float* coef_dev, float lr, float b1, float b2, void* stream);
+int tagrec_spmm_axpy_adam_graph_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                    const unsigned* in_count, const float* B, float b_scale, const uint8_t* b_flags,
+                                    float* p, float* m, float* v, float lr, float b1, float b2, float eps,
+                                    int64_t* step_dev, float* coef_dev, int D, void* stream);
 
 /* out = srcs[0] + ... + srcs[n_srcs - 1] (1 <= n_srcs <= 8, n floats each, summed left to right) in one pass: the
  * gradient of a table that several consumers read (what autograd's pairwise accumulation does in 3 passes per extra

@@ -18,6 +18,47 @@ def xavier_tables(num_list, dim, device):
     return torch.cat(parts, dim=0).to(device)
 
 
+class StepWorkspace:
+    """The [N, D]-sized buffers of a model's restricted training step, owned by the model and reused from step to step: no
+    allocator traffic inside the step (at the C5 shape the caching allocator held 298 GB reserved against a 180 GB peak),
+    and fixed addresses for a captured HIP graph.  One step at a time: `acquire(token)` hands the buffers to a forward pass;
+    they are free again when its backward pass has run (`release`) or its autograd context has been dropped (the token
+    died).  A forward pass that finds them taken -- two losses alive at once -- allocates its own buffers as before."""
+
+    def __init__(self):
+        self._buf = {}
+        self._owner = None
+
+    def acquire(self, token):
+        if self._owner is not None and self._owner() is not None:
+            return False
+        import weakref
+        self._owner = weakref.ref(token)
+        return True
+
+    def release(self, token):
+        if self._owner is not None and self._owner() is token:
+            self._owner = None
+
+    def get(self, name, shape, dtype, device):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
+            t = self._buf[name] = torch.empty(shape, dtype=dtype, device=device)
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._buf.values())
+
+
+class _Token:
+    pass
+
+
+def step_buffer(ws, name, shape, dtype, device):
+    """A workspace buffer when a workspace is in use, otherwise a fresh torch.empty."""
+    return torch.empty(shape, dtype=dtype, device=device) if ws is None else ws.get(name, shape, dtype, device)
+
+
 class TableModel(nn.Module):
     def _init_table(self, data, use_tag, dim, device):
         if torch.device(device).type != "cuda":

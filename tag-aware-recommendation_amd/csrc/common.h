@@ -77,6 +77,7 @@ __device__ __forceinline__ adam_f4 adam_update(adam_f4& mi, adam_f4& vi, adam_f4
 struct AdamRow {
   float* p; float* m; float* v;
   float w1, b2, w2, step_size, bc2_sqrt, eps;
+  const float* coef = nullptr;     // device [step_size, bc2_sqrt] advanced on the device (graph replay); overrides the two floats
 };
 
 }  // namespace tagrec

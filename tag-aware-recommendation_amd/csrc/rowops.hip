@@ -736,6 +736,14 @@ extern "C" int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* 
   return launch_adam(p, g, m, v, n, b1, b2, eps, 0.f, 1.f, coef_dev, s);
 }
 
+extern "C" int tagrec_adam_advance(int64_t* step_dev, float* coef_dev, float lr, float b1, float b2, void* stream) {
+  TAGREC_REQUIRE(step_dev && coef_dev, "adam_advance: null pointer");
+  adam_advance_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(step_dev, coef_dev, static_cast<double>(lr), static_cast<double>(b1),
+                                                                     static_cast<double>(b2));
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
 extern "C" int tagrec_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream) {
   TAGREC_REQUIRE(x && out, "dropout: null pointer");
   TAGREC_REQUIRE(n >= 0 && n % 4 == 0 && aligned16(x) && aligned16(out), "dropout: need a multiple of 4 elements, 16-byte aligned");

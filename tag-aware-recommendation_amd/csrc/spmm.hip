@@ -217,8 +217,10 @@ __device__ __forceinline__ void row_epilogue(float4 acc, int64_t r, int lane, co
         adam_f4 m = __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(e.adam.m) + off);
         adam_f4 v = __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(e.adam.v) + off);
         const adam_f4 p = __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(e.adam.p) + off);
-        const adam_f4 q = adam_update(m, v, p, adam_f4{o.x, o.y, o.z, o.w}, e.adam.w1, e.adam.b2, e.adam.w2, e.adam.step_size,
-                                      e.adam.bc2_sqrt, e.adam.eps);
+        const float step_size = e.adam.coef ? e.adam.coef[0] : e.adam.step_size;
+        const float bc2_sqrt = e.adam.coef ? e.adam.coef[1] : e.adam.bc2_sqrt;
+        const adam_f4 q = adam_update(m, v, p, adam_f4{o.x, o.y, o.z, o.w}, e.adam.w1, e.adam.b2, e.adam.w2, step_size, bc2_sqrt,
+                                      e.adam.eps);
         __builtin_nontemporal_store(m, reinterpret_cast<adam_f4*>(e.adam.m) + off);
         __builtin_nontemporal_store(v, reinterpret_cast<adam_f4*>(e.adam.v) + off);
         __builtin_nontemporal_store(q, reinterpret_cast<adam_f4*>(e.adam.p) + off);
@@ -1121,6 +1123,28 @@ extern "C" int tagrec_spmm_axpy_adam_f32(const tagrec_graph* g, const float* G_i
   e.adam = AdamRow{p, m, v, static_cast<float>(1.0 - static_cast<double>(b1)), b2, static_cast<float>(1.0 - static_cast<double>(b2)),
                    static_cast<float>(static_cast<double>(lr) / bc1), static_cast<float>(sqrt(bc2)), eps};
   return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_adam");
+}
+
+// The same with the step counter and the two step-dependent factors in DEVICE memory (advanced by a one-thread kernel in
+// front of the product), so the whole training step -- optimizer included -- can be captured once as a HIP graph and replayed.
+extern "C" int tagrec_adam_advance(int64_t* step_dev, float* coef_dev, float lr, float b1, float b2, void* stream);
+extern "C" int tagrec_spmm_axpy_adam_graph_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,
+                                               const unsigned* in_count, const float* B, float b_scale, const uint8_t* b_flags,
+                                               float* p, float* m, float* v, float lr, float b1, float b2, float eps,
+                                               int64_t* step_dev, float* coef_dev, int D, void* stream) {
+  TAGREC_REQUIRE(B != nullptr && p != nullptr && m != nullptr && v != nullptr && step_dev != nullptr && coef_dev != nullptr,
+                 "spmm_axpy_adam_graph: null pointer");
+  TAGREC_REQUIRE(in_flags != nullptr || in_count == nullptr, "spmm_axpy_adam_graph: in_count without in_flags");
+  TAGREC_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "spmm_axpy_adam_graph: D must be 8 .. 256, a power of two");
+  TAGREC_REQUIRE(static_cast<const void*>(G_in) != static_cast<const void*>(p), "spmm_axpy_adam_graph: the gathered operand aliases the parameters");
+  TAGREC_REQUIRE(aligned16(p) && aligned16(m) && aligned16(v) && aligned16(G_in) && aligned16(B),
+                 "spmm_axpy_adam_graph: every operand (p, m, v, G_in, B) must be 16-byte aligned");
+  int rc = tagrec_adam_advance(step_dev, coef_dev, lr, b1, b2, stream);
+  if (rc != TAGREC_OK) return rc;
+  EpiArgs e{p, nullptr, nullptr, nullptr, B, nullptr, b_scale, DropMask{0.f, 0}, in_flags, in_count, nullptr, nullptr, b_flags};
+  e.adam = AdamRow{p, m, v, static_cast<float>(1.0 - static_cast<double>(b1)), b2, static_cast<float>(1.0 - static_cast<double>(b2)),
+                   0.f, 1.f, eps, coef_dev};
+  return launch_spmm<EPI_AXPY>(g, G_in, e, D, stream, "spmm_axpy_adam_graph");
 }
 
 extern "C" int tagrec_spmm_normbwd_dot_sparse_f32(const tagrec_graph* g, const float* G_in, const uint8_t* in_flags,

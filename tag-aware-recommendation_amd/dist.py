@@ -326,6 +326,10 @@ class _Gather:
         block = block.contiguous()
         if getattr(m, "all_gather_mode", "collective") == "direct":
             rows = block.shape[0]
+            if block.is_cuda and dist.get_backend(m.group) != "nccl":
+                # rehearsal on a shared GPU over gloo: its point-to-point path reads the buffer from the host side without
+                # looking at HIP streams (RCCL orders the transfer behind the producing kernel by itself)
+                torch.cuda.current_stream(block.device).synchronize()
             dst[m.rank * rows:(m.rank + 1) * rows].copy_(block)                     # own slot: a local copy
             ops = []
             for d in range(1, m.world):                                                # peer order staggered by rank

@@ -406,13 +406,20 @@ class Graph:
                    _lib.ptr(g_in), _lib.ptr(in_flags), _lib.ptr(in_count), _lib.ptr(b), float(b_scale), _lib.ptr(g_out),
                    _lib.ptr(row_mask), _lib.ptr(b_flags), D, _lib.stream_ptr())
 
-    def spmm_axpy_adam(self, g_in, in_flags, in_count, b, b_scale, b_flags, p, m, v, lr, betas, eps, step):
+    def spmm_axpy_adam(self, g_in, in_flags, in_count, b, b_scale, b_flags, p, m, v, lr, betas, eps, step, dev=None):
         """The last hop with Adam folded in: row r of A g_in + b_scale b is the gradient of parameter row r and updates
-        p / m / v in the epilogue (no gradient tensor is written)."""
+        p / m / v in the epilogue (no gradient tensor is written).  dev = (step counter, factors) in device memory: the
+        capturable form (the counter is advanced on the stream, `step` is ignored)."""
         D = self._chk_x(g_in, self.shape[1], "spmm_axpy_adam g_in")
         for t, nm in ((b, "b"), (p, "p"), (m, "m"), (v, "v")):
             if self._chk_x(t, self.shape[0], "spmm_axpy_adam " + nm) != D:
                 raise _lib.TagrecError("spmm_axpy_adam: width mismatch on " + nm)
+        if dev is not None:
+            self._call("spmm_axpy", _lib.load().tagrec_spmm_axpy_adam_graph_f32, self._h, _lib.ptr(g_in), _lib.ptr(in_flags),
+                       _lib.ptr(in_count), _lib.ptr(b), float(b_scale), _lib.ptr(b_flags), _lib.ptr(p), _lib.ptr(m), _lib.ptr(v),
+                       float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.ptr(dev[0]), _lib.ptr(dev[1]), D,
+                       _lib.stream_ptr())
+            return
         self._call("spmm_axpy", _lib.load().tagrec_spmm_axpy_adam_f32, self._h, _lib.ptr(g_in), _lib.ptr(in_flags),
                    _lib.ptr(in_count), _lib.ptr(b), float(b_scale), _lib.ptr(b_flags), _lib.ptr(p), _lib.ptr(m), _lib.ptr(v),
                    float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), D, _lib.stream_ptr())

@@ -15,7 +15,7 @@ Differences in mechanism, not in results:
 import torch
 
 from . import _lib, help as H
-from .base import TableModel, xavier_tables  # noqa: F401  (xavier_tables re-exported)
+from .base import StepWorkspace, TableModel, _Token, step_buffer, xavier_tables  # noqa: F401  (xavier_tables re-exported)
 from .config import CFG as _GLOBAL_CFG
 from .graph import Graph, creat_adj
 from .train import fused_optimizer
@@ -113,7 +113,8 @@ def propagate_backward(graph_t, d_out, raws, invs, drops=None, seed=0, masks=Non
     if fused is not None and sparse:      # (table, optimizer): Adam in the epilogue of the last hop, no gradient tensor
         table, opt = fused
         m, v, step = opt.fused_state(table)
-        graph_t.spmm_axpy_adam(g, flags[cur], counts[cur:cur + 1], d_out, s, None, table.data, m, v, opt.lr, opt.betas, opt.eps, step)
+        graph_t.spmm_axpy_adam(g, flags[cur], counts[cur:cur + 1], d_out, s, None, table.data, m, v, opt.lr, opt.betas, opt.eps, step,
+                               opt.fused_dev(table))
         opt.fused_commit(table)
         return None
     g0 = torch.empty_like(d_out)
@@ -140,7 +141,7 @@ def spmm_listed(graph, rows, x, out=None):
     return out
 
 
-def restricted_forward(graph, x0, n_layer, rows):
+def restricted_forward(graph, x0, n_layer, rows, ws=None):
     """The forward pass of a training step whose loss reads the layer mean at `rows` (int64 node ids [T], may repeat)
     only -- the BPR batch rows (lightgcn.py:71-75).  Layers below L-1 run on all rows (through the popular items every
     row is within two hops of the batch), layer L-1 on the batch rows and their neighbours (row-masked kernel), layer L
@@ -150,12 +151,13 @@ def restricted_forward(graph, x0, n_layer, rows):
     L, s = n_layer, 1.0 / (n_layer + 1)
     n, D = x0.shape
     T = rows.numel()
-    mid = graph.mark_rows(rows, torch.zeros(n, dtype=torch.uint8, device=x0.device)) if L >= 2 else None
+    dev = x0.device
+    mid = graph.mark_rows(rows, step_buffer(ws, "mid", (n,), torch.uint8, dev).zero_()) if L >= 2 else None
     raws, invs = [], []
     x = x0
     for k in range(L - 1):
-        y = torch.empty_like(x0)
-        inv = torch.empty(n, dtype=torch.float32, device=x0.device)
+        y = step_buffer(ws, f"y{k}", (n, D), torch.float32, dev)
+        inv = step_buffer(ws, f"inv{k}", (n,), torch.float32, dev)
         graph.spmm_norm_acc_rows(x, y, inv, None, 0.0, mid if k == L - 2 else None)
         raws.append(y)
         invs.append(inv)
@@ -172,7 +174,7 @@ def restricted_forward(graph, x0, n_layer, rows):
     return out_b, (raws, invs, mid, y_top, inv_top)
 
 
-def restricted_backward(graph_t, rows, d_out_b, state, shape, fused=None):
+def restricted_backward(graph_t, rows, d_out_b, state, shape, fused=None, ws=None):
     """Gradient w.r.t. x0 of `restricted_forward` given d_out_b [T, D] = d loss / d out_b.  The chain starts on the batch
     rows (compact), lands on their neighbours (row-masked hop: G is non-zero there only) and spreads from there; every
     operand travels with one flag byte per row and zero rows are not gathered; the normalize-backward / mean terms exist
@@ -184,23 +186,25 @@ def restricted_backward(graph_t, rows, d_out_b, state, shape, fused=None):
     T = rows.numel()
     dev = d_out_b.device
     lib = _lib.load()
-    tflag = torch.zeros(n, dtype=torch.uint8, device=dev)
+    tflag = step_buffer(ws, "tflag", (n,), torch.uint8, dev).zero_()
     tflag.index_fill_(0, rows, 1)
-    dz = torch.empty(n, D, dtype=torch.float32, device=dev)             # d loss / d out, valid on the batch rows only
+    dz = step_buffer(ws, "dz", (n, D), torch.float32, dev)              # d loss / d out, valid on the batch rows only
     dz.index_fill_(0, rows, 0.0)
     dz.index_add_(0, rows, d_out_b)
     g_top = torch.empty(T, D, dtype=torch.float32, device=dev)
     _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(y_top), _lib.ptr(inv_top), _lib.ptr(d_out_b), D, s, _lib.ptr(g_top), 0, T, D,
                                           _lib.stream_ptr()), "rownorm_bwd")
-    g = torch.empty(n, D, dtype=torch.float32, device=dev)               # G^L: valid on the batch rows only (flags = tflag)
+    g = step_buffer(ws, "g_top", (n, D), torch.float32, dev)             # G^L: valid on the batch rows only (flags = tflag)
     g.index_fill_(0, rows, 0.0)
     g.index_add_(0, rows, g_top)
     flags, count = tflag, None                                           # count None: the flags are always consulted
     for k in range(L - 2, -1, -1):
         masked = k == L - 2
-        gn = torch.empty(n, D, dtype=torch.float32, device=dev)
-        fo = (torch.zeros if masked else torch.empty)(n, dtype=torch.uint8, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        gn = step_buffer(ws, f"g{k & 1}", (n, D), torch.float32, dev)
+        fo = step_buffer(ws, f"fo{k & 1}", (n,), torch.uint8, dev)
+        if masked:
+            fo.zero_()
+        cnt = step_buffer(ws, f"cnt{k & 1}", (1,), torch.int32, dev).zero_()
         graph_t.spmm_normbwd_sparse(g, flags, count, raws[k], invs[k], dz, s, gn, fo, cnt, row_mask=mid if masked else None,
                                     dz_flags=tflag)
         raws[k] = invs[k] = None          # last use: the 4 N D bytes go back to the allocator before the next hop allocates
@@ -209,10 +213,10 @@ def restricted_backward(graph_t, rows, d_out_b, state, shape, fused=None):
     if fused is not None:             # (table, optimizer): the last hop applies Adam to the table, no gradient is written
         table, opt = fused
         m, v, step = opt.fused_state(table)
-        graph_t.spmm_axpy_adam(g, flags, count, dz, s, tflag, table.data, m, v, opt.lr, opt.betas, opt.eps, step)
+        graph_t.spmm_axpy_adam(g, flags, count, dz, s, tflag, table.data, m, v, opt.lr, opt.betas, opt.eps, step, opt.fused_dev(table))
         opt.fused_commit(table)
         return None
-    g0 = torch.empty(n, D, dtype=torch.float32, device=dev)
+    g0 = torch.empty(n, D, dtype=torch.float32, device=dev)              # (handed to the optimizer: not a workspace buffer)
     graph_t.spmm_axpy_sparse(g, flags, count, dz, s, g0, b_flags=tflag)
     return g0
 
@@ -236,9 +240,12 @@ class _PropagateBprLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, graph, n_layer, n_user, n_item, trip, loss_kind, reg_active, drops=None, seed=0, restrict=True,
-                fused_opt=None):
+                fused_opt=None, ws=None):
         x0 = table.detach()
         ctx.fused = (table, fused_opt) if fused_opt is not None else None
+        ctx.ws, ctx.token = None, _Token()
+        if ws is not None and ws.acquire(ctx.token):
+            ctx.ws = ws
         B, D = trip.shape[0], x0.shape[1]
         n = x0.shape[0]
         lib = _lib.load()
@@ -251,7 +258,7 @@ class _PropagateBprLoss(torch.autograd.Function):
         ctx.compact = bool(restrict and drops is None and n_layer >= 1 and graph.shape[0] == graph.shape[1] and D in VEC_WIDTHS
                            and 3 * B * 16 <= n)                       # a batch that touches most rows gains nothing
         if ctx.compact:
-            out_b, ctx.state = restricted_forward(graph, x0, n_layer, rows)
+            out_b, ctx.state = restricted_forward(graph, x0, n_layer, rows, ctx.ws)
             ego_b = x0.index_select(0, rows)
             ar = torch.arange(B, device=x0.device)
             ctrip = torch.stack([ar, ar, ar + B], dim=1).contiguous()
@@ -289,11 +296,13 @@ class _PropagateBprLoss(torch.autograd.Function):
                                               _lib.ptr(d_b[1][:B]) if reg else null, _lib.ptr(d_b[1][B:]) if reg else null,
                                               _lib.stream_ptr()), "bpr_bwd")
             fused = ctx.fused if (ctx.fused is not None and not ctx.reg_active) else None
-            g0 = restricted_backward(ctx.graph.transpose(), rows, d_b[0], ctx.state, ctx.shape, fused)
+            g0 = restricted_backward(ctx.graph.transpose(), rows, d_b[0], ctx.state, ctx.shape, fused, ctx.ws)
             if ctx.reg_active:
                 g0.index_add_(0, rows, d_b[1])                            # L2 term on the ego rows
             ctx.state = ctx.out_b = None
-            return g0, None, None, None, None, None, None, None, None, None, None, None
+            if ctx.ws is not None:
+                ctx.ws.release(ctx.token)
+            return g0, None, None, None, None, None, None, None, None, None, None, None, None
         out, x0, trip = ctx.out, ctx.x0, ctx.trip
         nu, ni, D, B = ctx.n_user, ctx.n_item, x0.shape[1], trip.shape[0]
         d_out = torch.zeros_like(out)
@@ -312,7 +321,9 @@ class _PropagateBprLoss(torch.autograd.Function):
                                               null, null, _lib.ptr(g0[:nu]), _lib.ptr(g0[nu:nu + ni]),
                                               _lib.stream_ptr()), "bpr_bwd(reg)")
         ctx.raws = ctx.invs = ctx.out = None
-        return g0, None, None, None, None, None, None, None, None, None, None, None
+        if ctx.ws is not None:
+            ctx.ws.release(ctx.token)
+        return g0, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class LightGCN(TableModel):
@@ -337,9 +348,13 @@ class LightGCN(TableModel):
         self.drop_seed = config.get("seed", 2020)
         # loss(): compute the top two layers only on the rows the batch's loss depends on (propagate_forward)
         self.restrict_forward = bool(config.get("restrict_forward", True))
+        # persistent buffers of the restricted training step (base.StepWorkspace); config["step_workspace"] = False: allocate per step
+        self.step_ws = StepWorkspace() if config.get("step_workspace", True) else None
 
     def _fused_ok(self):
         return isinstance(self.norm_adj, Graph)
+
+    fused_capturable = True        # Adam(capturable=True).fuse_into(model): the fused update advances its counter on the device
 
     def set_fused_optimizer(self, opt):
         """`Adam.fuse_into(model)`: the compact restricted step (reg == 0) applies the table's Adam update in the epilogue of
@@ -388,7 +403,7 @@ class LightGCN(TableModel):
             fused = fused_optimizer(self) if (self.training and torch.is_grad_enabled()) else None
             res = _PropagateBprLoss.apply(self.table, self._graph(), self.num_layer, nu, ni, batch_data,
                                           H.loss_kind_id(self.loss_func), self.reg != 0, drops, seed, self.restrict_forward,
-                                          fused)
+                                          fused, self.step_ws if (self.training and torch.is_grad_enabled()) else None)
             return res[0], self.reg * res[1]
         all_users, all_items = self.forward()[:2]
         ego = self.embed

@@ -281,7 +281,8 @@ def restricted_backward(graph_t, rows, d_b, state, dims, n, fused=None):
         if fused is not None:
             table, opt = fused
             m_, v_, step = opt.fused_state(table)
-            graph_t.spmm_axpy_adam(g_in, in_flags, None, addend, 1.0, b_flags, table.data, m_, v_, opt.lr, opt.betas, opt.eps, step)
+            graph_t.spmm_axpy_adam(g_in, in_flags, None, addend, 1.0, b_flags, table.data, m_, v_, opt.lr, opt.betas, opt.eps, step,
+                                   opt.fused_dev(table))
             opt.fused_commit(table)
             return None
         out = torch.empty(n, dims[0], dtype=torch.float32, device=dev)
@@ -436,6 +437,8 @@ class NGCF(TableModel):
 
     def _mats(self):
         return [self.mat[f"{n}_{k}"] for k in range(self.num_layer) for n in ("W1", "b1", "W2", "b2")]
+
+    fused_capturable = True
 
     def set_fused_optimizer(self, opt):
         """`Adam.fuse_into(model)`: the compact restricted step applies the TABLE's Adam update in the epilogue of the product

@@ -40,14 +40,16 @@ class Adam:
         """Let `model` apply this optimizer's update of its embedding table inside the last kernel of its backward pass
         (the gradient row is consumed where it is formed: no gradient tensor, no separate Adam launch over the table).
         The zero_grad() / backward() / step() protocol of basic_train.py:19-25 is unchanged: step() then only counts
-        the step for that parameter.  One backward() per step(); not available with capturable=True.  Models without
-        the hook ignore the call.
+        the step for that parameter.  One backward() per step().  With capturable=True (models that declare
+        `fused_capturable`: LightGCN, NGCF) the step counter and the step-dependent factors live in device memory and
+        are advanced inside the fused launch, so the whole step can be captured as a HIP graph (`GraphedStep`).  Models
+        without the hook ignore the call.
 
         CONTRACT: with the fusion on, a training-mode backward() of `model.loss` CHANGES the table (and exp_avg /
         exp_avg_sq) -- also one that is not followed by step() (gradient inspection, clipping); a second such
         backward() before step() raises.  Use an un-fused optimizer for anything but the plain loop."""
-        if self.capturable:
-            raise _lib.TagrecError("Adam.fuse_into: the fused update keeps its step counter on the host (capturable=False)")
+        if self.capturable and not getattr(model, "fused_capturable", False):
+            raise _lib.TagrecError("Adam.fuse_into: this model's fused update keeps its step counter on the host (capturable=False)")
         if hasattr(model, "set_fused_optimizer"):
             table = getattr(model, "table", None)
             if table is not None and not any(q is table for q in self.params):
@@ -65,7 +67,15 @@ class Adam:
         st = self.state.get(id(p))
         if st is None:
             st = self.state[id(p)] = {"m": torch.zeros_like(p.data), "v": torch.zeros_like(p.data), "t": 0}
+            if self.capturable:
+                st["t_dev"] = torch.zeros(1, dtype=torch.int64, device=p.device)
+                st["coef"] = torch.zeros(2, dtype=torch.float32, device=p.device)
         return st["m"], st["v"], st["t"] + 1
+
+    def fused_dev(self, p):
+        """(device step counter, device factors) of a capturable optimizer's parameter, else None."""
+        st = self.state.get(id(p))
+        return (st["t_dev"], st["coef"]) if (self.capturable and st is not None) else None
 
     def fused_commit(self, p):
         """The fused update of `p` has been launched: step() only counts the step for it."""

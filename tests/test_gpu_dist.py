@@ -224,7 +224,7 @@ def test_bench_starts_its_own_ranks(parallel):
     c = line["extra"]["collectives"]
     assert c["world_size_seen_by_torch_distributed"] == 2 and c["bytes_exchanged_per_rank_per_step"] > 0
     if parallel == "row":
-        assert c["row_blocks_per_shard"] >= 1 and c["probe"]["all_gather_block_ms"] > 0
+        assert c["row_blocks_per_shard"] >= 1 and c["probe"]["all_gather_block_collective_ms"] > 0 and c["probe"]["all_gather_block_direct_GBs_in"] > 0
         assert "all_gather_wait" in c["compute_stream_wait_ms_per_step"]
     else:
         assert c["columns_per_rank"] == 32 and c["collectives_per_step"]["all_reduce"] == 3.0    # norms, dots, nb dots
