@@ -429,6 +429,18 @@ int tagrec_tgcn_attn_bwd_ds_f32(const float* P, const float* Q, const float* WT,
 int tagrec_attn_pull_dq_f32(const tagrec_graph* inv, const float* comp, const float* v, int A, const float* B, float* dQ,
                             void* stream);
 int tagrec_attn_keys_i32(const int32_t* idx, int64_t n, int32_t n_dst, int32_t* key, void* stream);
+/*   tagrec_inv_filter_i32 : a step's inverted table WITHOUT a sort.  The neighbour tables are static (tgcn.py:194-202), so each
+ *   relation's pair list sorted by destination is built once: perm_sorted (pair id v k + n of a non-pad slot) and dest_sorted
+ *   (its destination id), n_entries of them.  A step computes a row subset: pos_src[v + 1] = 1 + position of source row v in
+ *   it (0 = not computed; int32 [n_src + 1]); the entries of those rows are compacted IN ORDER into skey (destination,
+ *   renumbered through pos_dst[d + 1] - 1 when pos_dst != NULL), pair (= position k + slot), src (= position) and val
+ *   (= attn[pair]); skey[total .. capacity) is set to n_dst ("no entry").  capacity >= the number of listed entries (rows k
+ *   is always enough).  workspace: tagrec_inv_filter_workspace(n_entries) int32; workspace[blocks] = the total on return. */
+int64_t tagrec_inv_filter_workspace(int64_t n_entries);
+int tagrec_inv_filter_i32(const int32_t* perm_sorted, const int32_t* dest_sorted, int64_t n_entries, int k,
+                          const int32_t* pos_src, const int32_t* pos_dst, const float* attn, int32_t n_dst,
+                          int64_t capacity, int32_t* skey, int32_t* pair, int32_t* src, float* val,
+                          int32_t* workspace, int64_t workspace_ints, void* stream);
 /*   tagrec_nbr_gather_i32 : the neighbour tables of a ROW SUBSET in compact numbering (tgcn.py:194-202 restricted to the rows a
  *   mini-batch needs): out_idx[i, :] = pos[idx[rows[i], :]] (pos NULL: ids unchanged; pos[0] = 0 keeps the pad),
  *   out_widx[i, :] = widx[rows[i], :]. */

@@ -77,6 +77,9 @@ _SIGNATURES = {
     "tagrec_attn_pull_dq_f32": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "tagrec_attn_seg_dq_f32": [c_void_p, c_void_p, c_int64, ctypes.c_int32, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "tagrec_nbr_gather_i32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
+    "tagrec_inv_filter_workspace": [c_int64],
+    "tagrec_inv_filter_i32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_int32, c_int64, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "tagrec_attn_keys_i32": [c_void_p, c_int64, ctypes.c_int32, c_void_p, c_void_p],
     "tagrec_tgcn_fuse_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 12,
     "tagrec_tgcn_fuse_bwd_workspace": [c_int],

@@ -89,6 +89,18 @@ __global__ __launch_bounds__(kProjThreads) void tall_mm_kernel(TallArgs a, Small
       if (a.Y2 && c >= NO / 2) { b = a.b2; cc = c - NO / 2; }
       acc[cb] = b ? *reinterpret_cast<const pj4*>(b + cc) : pj4{0.f, 0.f, 0.f, 0.f};
     }
+    // accumulate form: what the destination holds is fetched NOW, beside the operand rows, not behind the MFMA chain
+    pj4 old[CB];
+    if (a.accumulate) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int c = 16 * cb + 4 * g;
+        const float* dst;
+        if (a.Y2) dst = c < NO / 2 ? a.Y1 + row * (NO / 2) + c : a.Y2 + row * (NO / 2) + (c - NO / 2);
+        else dst = a.Y1 + row * NO + c;
+        old[cb] = ok ? *reinterpret_cast<const pj4*>(dst) : pj4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
 #pragma unroll
     for (int j = 0; j < KJ; ++j)
 #pragma unroll
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(kProjThreads) void tall_mm_kernel(TallArgs a, Small
         if (a.Y2) dst = c < NO / 2 ? a.Y1 + row * (NO / 2) + c : a.Y2 + row * (NO / 2) + (c - NO / 2);
         else dst = a.Y1 + row * NO + c;
         pj4 o = acc[cb];
-        if (a.accumulate) o += *reinterpret_cast<const pj4*>(dst);
+        if (a.accumulate) o += old[cb];
         *reinterpret_cast<pj4*>(dst) = o;
       }
     }

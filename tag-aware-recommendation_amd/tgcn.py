@@ -45,6 +45,10 @@ class InverseTable:
         dest = flat[pos] - 1
         order = torch.argsort(dest, stable=True)
         self.perm = pos[order].contiguous()
+        # the same list as int32 + the destination of every entry: what the sort-free per-step inversion compacts
+        # (tagrec_inv_filter_i32)
+        self.perm32 = self.perm.to(torch.int32)
+        self.dest32 = dest[order].to(torch.int32).contiguous()
         rowptr = torch.zeros(n_dst + 1, dtype=torch.int64, device=idx.device)
         torch.cumsum(torch.bincount(dest, minlength=n_dst), 0, out=rowptr[1:])
         ones = torch.ones(self.perm.numel(), dtype=torch.float32, device=idx.device)

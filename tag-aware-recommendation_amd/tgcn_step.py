@@ -81,7 +81,10 @@ def attn_bwd(P, Q, WT, v, Ej, idx, widx, attn, d_out, dQ, dEj, dh):
     return dP, dWT, dv
 
 
-def attn_bwd_pulls(P, Q, WT, v, Ej, idx, widx, attn, d_out, addQ, addX, w_major=-1, out=None):
+STATIC_INVERSION_MIN_SHARE = 0.05      # use the sort-free inversion when the step's rows hold at least this share of a relation's pairs
+
+
+def attn_bwd_pulls(P, Q, WT, v, Ej, idx, widx, attn, d_out, addQ, addX, w_major=-1, out=None, static=None):
     """The attention backward of one relation in pull form without the dh round trip (include/tagrec.h): the relation's
     table of this step's rows is inverted on the spot (one radix sort of the n k destination ids; pads sort behind the last
     row), then  dEj (+ addX) and da  <-  attn_pull_da;  dP, dWT, dv, (ds, relu bits)  <-  attn_bwd_ds;  dQ (+ addQ)  <-
@@ -93,15 +96,26 @@ def attn_bwd_pulls(P, Q, WT, v, Ej, idx, widx, attn, d_out, addQ, addX, w_major=
     k, n_wt = idx.shape[1], WT.shape[0]
     n_dst, D = Ej.shape
     dev = P.device
-    key = torch.empty(n * k, dtype=torch.int32, device=dev)
-    _lib.check(lib.tagrec_attn_keys_i32(_lib.ptr(idx), n * k, n_dst, _lib.ptr(key), _lib.stream_ptr()), "attn_keys")
-    skey, order = torch.sort(key, stable=True)
-    rowptr = torch.searchsorted(skey, torch.arange(n_dst + 1, dtype=torch.int32, device=dev))
     pair = torch.empty(n * k, dtype=torch.int32, device=dev)
     src = torch.empty(n * k, dtype=torch.int32, device=dev)
     val = torch.empty(n * k, dtype=torch.float32, device=dev)
-    _lib.check(lib.tagrec_attn_invert_fill(_lib.ptr(order), _lib.ptr(attn), k, n * k, _lib.ptr(pair), _lib.ptr(src), _lib.ptr(val),
-                                           _lib.stream_ptr()), "attn_invert_fill")
+    if static is not None:
+        # the relation's pair list sorted by destination exists since start-up (the tables are static): compact the entries
+        # of this step's rows in order -- no sort
+        perm32, dest32, pos_src, pos_dst = static
+        skey = torch.empty(n * k, dtype=torch.int32, device=dev)
+        fw_n = lib.tagrec_inv_filter_workspace(perm32.numel())
+        fw = torch.empty(fw_n, dtype=torch.int32, device=dev)
+        _lib.check(TG._timed("attn_invert", lib.tagrec_inv_filter_i32, _lib.ptr(perm32), _lib.ptr(dest32), perm32.numel(), k,
+                             _lib.ptr(pos_src), _lib.ptr(pos_dst), _lib.ptr(attn), n_dst, n * k, _lib.ptr(skey), _lib.ptr(pair),
+                             _lib.ptr(src), _lib.ptr(val), _lib.ptr(fw), fw_n, _lib.stream_ptr()), "inv_filter")
+    else:
+        key = torch.empty(n * k, dtype=torch.int32, device=dev)
+        _lib.check(lib.tagrec_attn_keys_i32(_lib.ptr(idx), n * k, n_dst, _lib.ptr(key), _lib.stream_ptr()), "attn_keys")
+        skey, order = torch.sort(key, stable=True)
+        _lib.check(lib.tagrec_attn_invert_fill(_lib.ptr(order), _lib.ptr(attn), k, n * k, _lib.ptr(pair), _lib.ptr(src), _lib.ptr(val),
+                                               _lib.stream_ptr()), "attn_invert_fill")
+    rowptr = torch.searchsorted(skey, torch.arange(n_dst + 1, dtype=torch.int32, device=dev))
     inv = Graph(rowptr, src, val, (n_dst, n), workspace=True)
     da = torch.empty(n * k, dtype=torch.float32, device=dev)
     dEj = out if out is not None else torch.empty(n_dst, D, dtype=torch.float32, device=dev)      # (may alias addX: element-wise)
@@ -201,8 +215,8 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
             lo[t], M = M, M + m[t]
         rng = {t: slice(lo[t], lo[t] + m[t]) for t in TYPES}
         T3 = [torch.empty(M, D, dtype=torch.float32, device=dev) for _ in range(3)]      # (user-, item-, tag-side) vectors
-        st = {"rows_out": rows_out, "rows_in": rows_in, "X": X, "att": att, "dp": dp, "ewp": ewp, "own": own, "m": m, "rng": rng,
-              "M": M, "T3": T3}
+        st = {"rows_out": rows_out, "rows_in": rows_in, "pos_in": pos_in, "X": X, "att": att, "dp": dp, "ewp": ewp, "own": own, "m": m,
+              "rng": rng, "M": M, "T3": T3}
         sel, Xs, Q, P = {}, {}, {}, {}
         for t, (n1, n2) in OTHERS.items():
             Xs[t] = T3[SLOT[t]][rng[t]]                     # the rows' own vectors: the type's slot of the triple
@@ -274,7 +288,7 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
                 _lib.check(lib.tagrec_rownorm_fwd_f32(_lib.ptr(xr), _lib.ptr(cat[t][:, off:]), dtot, _lib.ptr(inv), n_top[t], d_out,
                                                       _lib.stream_ptr()), "rownorm_fwd")
             norm_saved[t] = (xr, inv)
-        st.update(extra=extra, norm=norm_saved, off=off)
+        st.update(extra=extra, norm=norm_saved, off=off, pos_out=pos_out)
         saved.append(st)
         off += d_out
         X, rows_in, pos_in = Od, rows_out, pos_out
@@ -367,9 +381,14 @@ def step_backward(model, g, state, n_weight):
             if pull and A in (16, 32):
                 # destination-centric pull of dEj (+ da on the way), source-centric softmax backward from da (8 bytes per pair
                 # out), destination-centric pull of dQ from the compressed pairs
+                static = None
+                inv_r = model.inv[r] if model.inv is not None else None
+                if (inv_r is not None and rows_out[src] is not None
+                        and m[src] * k >= STATIC_INVERSION_MIN_SHARE * inv_r.perm32.numel()):
+                    static = (inv_r.perm32, inv_r.dest32, st["pos_out"][src], st["pos_in"][nb])
                 dP[r], dWT_r, dv_r, accQ[nb], _ = attn_bwd_pulls(
                     st["P"][(src, nb)], st["Q"][nb], st["WT"][nb], att[nb][3].reshape(-1), X[nb], idx, widx, st["attns"][r], d_out,
-                    accQ[nb], dx[nb] if have_x[nb] else None, model.w_major[r], out=dx[nb])
+                    accQ[nb], dx[nb] if have_x[nb] else None, model.w_major[r], out=dx[nb], static=static)
                 have_x[nb] = True
             else:
                 if pull:

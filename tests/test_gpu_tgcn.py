@@ -559,6 +559,52 @@ def test_attention_backward_pulls_without_dh_equal_the_scatter_form(n, n_nbr, k,
         TS.SEGMENTED_DQ = old
 
 
+@pytest.mark.parametrize("renumber_dst", [False, True])
+def test_sort_free_inversion_of_a_row_subset_equals_the_sorted_one(renumber_dst):
+    """tagrec_inv_filter_i32: a step's inverted table as an order-preserving compaction of the relation's static pair list
+    (sorted by destination once, at model start-up) instead of a radix sort per step -- same destination order, so the pulls
+    sum in the same order: skey / pair / src / val identical to the sorted path's, and the attention backward built on it
+    gives the same dP, dWT, dv, dQ, dEj.  With pads, a popular destination, rows outside the subset, and (renumber_dst) the
+    destination table compact as well (layer >= 2 of the restricted step)."""
+    from tagrec_amd import tgcn as TG, tgcn_step as TS
+    n_all, n_nbr_all, k, D, A, n_wt = 5000, 3000, 7, 64, 32, 5
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    rnd = lambda *s_: (torch.randn(*s_, generator=gen) * 0.3).to(DEV)
+    idx_full = torch.randint(0, n_nbr_all + 1, (n_all, k), generator=gen)
+    idx_full[:, 0] = 5
+    idx_full[::4, 2] = 0
+    if renumber_dst:                       # destinations restricted to a subset that holds every listed neighbour
+        keep = torch.unique(torch.cat([torch.randperm(n_nbr_all, generator=gen)[:1200], torch.tensor([4])]))
+        idx_full = torch.where(idx_full > 0, keep[torch.randint(0, keep.numel(), idx_full.shape, generator=gen)] + 1, idx_full)
+        idx_full[:, 0] = 5
+        pos_dst = torch.zeros(n_nbr_all + 1, dtype=torch.int32)
+        pos_dst[keep + 1] = torch.arange(1, keep.numel() + 1, dtype=torch.int32)
+        n_dst = keep.numel()
+    else:
+        pos_dst, n_dst = None, n_nbr_all
+    idx_full = idx_full.to(DEV).to(torch.int32).contiguous()
+    widx_full = torch.randint(0, n_wt, (n_all, k), generator=gen).to(DEV).to(torch.int32)
+    inv = TG.InverseTable(idx_full, n_nbr_all)
+    rows = torch.sort(torch.randperm(n_all, generator=gen)[:2100])[0].to(DEV)
+    n = rows.numel()
+    pos_src = torch.zeros(n_all + 1, dtype=torch.int32, device=DEV)
+    pos_src[rows + 1] = torch.arange(1, n + 1, dtype=torch.int32, device=DEV)
+    idx_c, widx_c = idx_full[rows], widx_full[rows].contiguous()
+    if pos_dst is not None:
+        pos_dst = pos_dst.to(DEV)
+        idx_c = pos_dst[idx_c.long()]
+    idx_c = idx_c.contiguous()
+    P, Q, WT, v, Ej, d_out = rnd(n, A), rnd(n_dst, A), rnd(n_wt, A), rnd(A), rnd(n_dst, D), rnd(n, D)
+    _, attn = TS.attn_fwd(P, Q, WT, v, Ej, idx_c, widx_c)
+    want = TS.attn_bwd_pulls(P, Q, WT, v, Ej, idx_c, widx_c, attn, d_out, None, None)
+    got = TS.attn_bwd_pulls(P, Q, WT, v, Ej, idx_c, widx_c, attn, d_out, None, None, static=(inv.perm32, inv.dest32, pos_src, pos_dst))
+    for name, a, b in zip(("dP", "dWT", "dv", "dQ", "dEj"), want, got):
+        scale = float(a.abs().max()) + 1e-30
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale, err_msg=name)
+    # dEj sums in the same order on both paths: bit-identical
+    assert torch.equal(want[4], got[4])
+
+
 def test_tall_projection_weight_gradient_by_slabs():
     """`_TallMM`: X @ W whose weight gradient is summed slab by slab (n not a multiple of the slab count)."""
     from tagrec_amd import tgcn as TG
