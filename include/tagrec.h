@@ -465,6 +465,19 @@ int tagrec_tgcn_fuse_fwd_f32(const float* T0, const float* T1, const float* T2, 
                              const float* wb, const float* w1, const float* w2, const float* w3,
                              const float* Wf, const float* bf, float* bw_out, float* out, void* stream);
 
+/*   fwd with MESSAGE DROPOUT of the output (F.dropout on eu / ei / et, tgcn.py:217-219) in the epilogue: the n rows are up to
+ *        three segments [0, lo1), [lo1, lo2), [lo2, n) -- the node types of a layer, merged into one launch -- each with its own
+ *        seed (host array seeds3) and, when the launch computes a row subset, its node ids (rowsK, device int64; NULL = rows
+ *        0 .. in order).  out = mask(seed, node id, column) relu(..) / (1 - p) with the counter-based mask of
+ *        tagrec_dropout_rows_f32.  The backward entry points are used unchanged with out' = this output and dOut' =
+ *        dOut / (1 - p): [out' > 0] = mask [out > 0]. */
+int tagrec_tgcn_fuse_fwd_drop_f32(const float* T0, const float* T1, const float* T2, int64_t n, int D, int Dout,
+                                  int A, int C, int V, const float* U, const float* q, const float* p,
+                                  const float* wb, const float* w1, const float* w2, const float* w3,
+                                  const float* Wf, const float* bf, float drop_p, const uint64_t* seeds3,
+                                  const int64_t* rows0, const int64_t* rows1, const int64_t* rows2, int64_t lo1,
+                                  int64_t lo2, float* bw_out, float* out, void* stream);
+
 /*   bwd (data part): from dOut [n, Dout] and the forward's `out` (ReLU mask): dT0/dT1/dT2 [n, D]; yvec [n, 6V]
  *        (post-ReLU vector features) and dfeat [n, 6V] (their pre-activation gradients), dS [n, 3A] (type-attention
  *        pre-activation gradients) for the weight gradients; small [3C + 2A] = dwb | dq | dp
@@ -519,11 +532,14 @@ int tagrec_masked_colsum_f32(const float* dOut, const float* out, int64_t n_rows
                              int64_t workspace_floats, void* stream);
 
 /* ---- bandwidth probes (measured ceilings of the box next to the 8 TB/s specification) ----------------
- * a = b + s * c over n floats (stream triad; 12 bytes per element), and a random whole-row gather with the access shape
+ * a = b + s * c over n floats (stream triad; 12 bytes per element; c == NULL: copy a = b, 8 bytes per element; non_temporal
+ * picks the load / store flavour), and a random whole-row gather with the access shape
  * of the SpMM's neighbour gather (64 rows of D floats per wavefront and index chunk, nothing else): sums of the gathered
  * rows land in out[tagrec_probe_gather_out_floats()], which exists only to keep the loads alive.  Indices are NOT
  * range-checked on the device: the caller guarantees 0 <= idx[i] < n_rows. */
-int tagrec_probe_triad_f32(float* a, const float* b, const float* c, float s, int64_t n, void* stream);
+int tagrec_probe_triad_f32(float* a, const float* b, const float* c, float s, int64_t n, int non_temporal, void* stream);
+/* read-only stream over n floats; out holds tagrec_probe_gather_out_floats() floats (per-thread sums that keep the loads alive) */
+int tagrec_probe_read_f32(const float* b, int64_t n, float* out, void* stream);
 int64_t tagrec_probe_gather_out_floats(void);
 int tagrec_probe_gather_rows_f32(const float* table, int64_t n_rows, int D, const int32_t* idx, int64_t n_idx, float* out,
                                  void* stream);

@@ -82,6 +82,8 @@ _SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "tagrec_attn_keys_i32": [c_void_p, c_int64, ctypes.c_int32, c_void_p, c_void_p],
     "tagrec_tgcn_fuse_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 12,
+    "tagrec_tgcn_fuse_fwd_drop_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9
+                                     + [c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
     "tagrec_tgcn_fuse_bwd_workspace": [c_int],
     "tagrec_tgcn_fuse_bwd_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 18
                                 + [c_int64, c_void_p],
@@ -143,7 +145,8 @@ _SIGNATURES = {
     "tagrec_masked_colsum_workspace": [c_int],
     "tagrec_masked_colsum_f32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p],
     "tagrec_row_add_at_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
-    "tagrec_probe_triad_f32": [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p],
+    "tagrec_probe_triad_f32": [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p],
+    "tagrec_probe_read_f32": [c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_probe_gather_out_floats": [],
     "tagrec_probe_gather_rows_f32": [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_adam_advance": [c_void_p, c_void_p, c_float, c_float, c_float, c_void_p],

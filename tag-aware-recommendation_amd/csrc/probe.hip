@@ -14,14 +14,29 @@ namespace {
 
 typedef float pf4 __attribute__((ext_vector_type(4)));
 
+// NT = non-temporal loads / stores (lines not retained in the caches); c == nullptr: plain copy a = b (8 bytes per element)
+template <bool NT>
 __global__ __launch_bounds__(256) void probe_triad_kernel(pf4* __restrict__ a, const pf4* __restrict__ b,
                                                            const pf4* __restrict__ c, float s, int64_t n4) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += stride) {
-    const pf4 x = __builtin_nontemporal_load(b + i);
-    const pf4 y = __builtin_nontemporal_load(c + i);
-    __builtin_nontemporal_store(x + s * y, a + i);
+    pf4 x = NT ? __builtin_nontemporal_load(b + i) : b[i];
+    if (c) x += s * (NT ? __builtin_nontemporal_load(c + i) : c[i]);
+    if (NT) __builtin_nontemporal_store(x, a + i); else a[i] = x;
   }
+}
+
+// read-only stream: every thread sums its float4s and stores one value at the end (the SpMM moves 50x more bytes in than out)
+__global__ __launch_bounds__(256) void probe_read_kernel(const pf4* __restrict__ b, int64_t n4, pf4* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  pf4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    acc0 += __builtin_nontemporal_load(b + i);
+    acc1 += __builtin_nontemporal_load(b + i + stride);
+  }
+  if (i < n4) acc0 += __builtin_nontemporal_load(b + i);
+  out[static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x] = acc0 + acc1;
 }
 
 // LPR = lanes per row (D / 4).  A wave walks chunks of 64 indices: every lane loads one index, the indices are handed
@@ -51,14 +66,28 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const pf4* __restrict
 
 using namespace tagrec;
 
-extern "C" int tagrec_probe_triad_f32(float* a, const float* b, const float* c, float s, int64_t n, void* stream) {
-  TAGREC_REQUIRE(a && b && c, "probe_triad: null pointer");
-  TAGREC_REQUIRE(n >= 0 && n % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(c), "probe_triad: need a multiple of 4 elements, 16-byte aligned");
+extern "C" int tagrec_probe_triad_f32(float* a, const float* b, const float* c, float s, int64_t n, int non_temporal, void* stream) {
+  TAGREC_REQUIRE(a && b, "probe_triad: null pointer");
+  TAGREC_REQUIRE(n >= 0 && n % 4 == 0 && aligned16(a) && aligned16(b) && (!c || aligned16(c)), "probe_triad: need a multiple of 4 elements, 16-byte aligned");
   if (n == 0) return TAGREC_OK;
   int64_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 256 * 8) blocks = 256 * 8;
-  probe_triad_kernel<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      reinterpret_cast<pf4*>(a), reinterpret_cast<const pf4*>(b), reinterpret_cast<const pf4*>(c), s, n / 4);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (non_temporal)
+    probe_triad_kernel<true><<<static_cast<unsigned>(blocks), 256, 0, st>>>(reinterpret_cast<pf4*>(a), reinterpret_cast<const pf4*>(b),
+                                                                           reinterpret_cast<const pf4*>(c), s, n / 4);
+  else
+    probe_triad_kernel<false><<<static_cast<unsigned>(blocks), 256, 0, st>>>(reinterpret_cast<pf4*>(a), reinterpret_cast<const pf4*>(b),
+                                                                            reinterpret_cast<const pf4*>(c), s, n / 4);
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_probe_read_f32(const float* b, int64_t n, float* out, void* stream) {
+  TAGREC_REQUIRE(b && out, "probe_read: null pointer");
+  TAGREC_REQUIRE(n >= 0 && n % 4 == 0 && aligned16(b) && aligned16(out), "probe_read: need a multiple of 4 elements, 16-byte aligned");
+  if (n == 0) return TAGREC_OK;
+  probe_read_kernel<<<256 * 8, 256, 0, static_cast<hipStream_t>(stream)>>>(reinterpret_cast<const pf4*>(b), n / 4, reinterpret_cast<pf4*>(out));
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

@@ -47,6 +47,31 @@ __device__ __forceinline__ float quad_sum(float v) {   // over the 4 lanes that 
   return v;
 }
 
+// Message dropout of the layer's output (F.dropout on eu / ei / et, /root/reference/model/tgcn.py:217-219) in the forward
+// kernel's epilogue.  One launch covers up to three row segments (the node types of a layer, merged: [0, lo1) users,
+// [lo1, lo2) items, [lo2, n) tags), each with its own seed and -- when the launch computes a row SUBSET -- its list of
+// node ids: the mask of element (row, column) is the counter-based one of common.h keyed by (seed, NODE id, column), so
+// the restricted step on compact tables and an all-rows pass drop the same elements.  The backward pass needs nothing
+// new: with out' = mask out / (1 - p) stored, [out' > 0] = mask [out > 0], so g = dOut' / (1 - p) [out' > 0].
+struct FuseDrop {
+  float p;                         // 0 = off
+  int64_t lo1, lo2;
+  const int64_t* rows[3];          // nullptr: the segment's rows are nodes 0 .. in order
+  uint64_t seed[3];
+};
+template <int OS, int DOUT>
+__device__ __forceinline__ void fuse_drop(const FuseDrop& d, int64_t node, int q, float (&o)[OS]) {
+  if (d.p <= 0.f) return;
+  const int seg = node >= d.lo2 ? 2 : (node >= d.lo1 ? 1 : 0);
+  const int64_t local = node - (seg == 2 ? d.lo2 : (seg == 1 ? d.lo1 : 0));
+  const int64_t* rows = seg == 2 ? d.rows[2] : (seg == 1 ? d.rows[1] : d.rows[0]);
+  const uint64_t seed = seg == 2 ? d.seed[2] : (seg == 1 ? d.seed[1] : d.seed[0]);
+  const int64_t id = rows ? rows[local] : local;
+  const DropMask m{d.p, seed};
+#pragma unroll
+  for (int i = 0; i < OS; i += 4) drop4(m, id * (DOUT / 4) + (q * OS + i) / 4, o[i], o[i + 1], o[i + 2], o[i + 3]);
+}
+
 // Launder a (wave-uniform) pointer inside the tile loop: without it the compiler proves the weight loads
 // loop-invariant, hoists hundreds of them out of the loop and holds them in registers (spilling the rest).
 __device__ __forceinline__ const float* fresh(const float* p) {
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_fwd_kernel(
     const float* __restrict__ U, const float* __restrict__ qv, const float* __restrict__ pv,
     const float* __restrict__ wb, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ w3, const float* __restrict__ Wf, const float* __restrict__ bf,
-    float* __restrict__ bw_out, float* __restrict__ out) {
+    float* __restrict__ bw_out, float* __restrict__ out, FuseDrop drop) {
   constexpr int DS = D / 4, OS = DOUT / 4, OB = DOUT / 16, AB = A / 16;
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
@@ -261,6 +286,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_fwd_kernel(
       for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
         for (int v = 0; v < 4; ++v) o[v * OB + ob] = fmaxf(acc[s][ob][v] + bf[q * OS + v * OB + ob], 0.f);
+      fuse_drop<OS, DOUT>(drop, node[s], q, o);
       float* dst = out + node[s] * DOUT + q * OS;
 #pragma unroll
       for (int i = 0; i < OS; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_fwd_lds_kernel(
     const float* __restrict__ U, const float* __restrict__ qv, const float* __restrict__ pv,
     const float* __restrict__ wb, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ w3, const float* __restrict__ Wf, const float* __restrict__ bf,
-    float* __restrict__ bw_out, float* __restrict__ out) {
+    float* __restrict__ bw_out, float* __restrict__ out, FuseDrop drop) {
   constexpr int DS = D / 4, OS = DOUT / 4, OB = DOUT / 16, AB = A / 16;
   constexpr int NEC = DS / kEC;                         // chunks per bit-level filter
   constexpr int RP = 256 / DOUT;                        // LDS rows per 1 KiB piece
@@ -391,6 +417,7 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_fwd_lds_kernel(
       for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
         for (int v = 0; v < 4; ++v) o[v * OB + ob] = fmaxf(acc[ob][v] + bf[q * OS + v * OB + ob], 0.f);
+      fuse_drop<OS, DOUT>(drop, node, q, o);
       float* dst = out + node * DOUT + q * OS;
 #pragma unroll
       for (int i = 0; i < OS; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
@@ -402,11 +429,11 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_fwd_lds_kernel(
 template <int D, int DOUT>
 int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n, const float* U, const float* qv,
                     const float* pv, const float* wb, const float* w1, const float* w2, const float* w3, const float* Wf,
-                    const float* bf, float* bw_out, float* out, hipStream_t s) {
+                    const float* bf, float* bw_out, float* out, const FuseDrop& drop, hipStream_t s) {
   if constexpr ((D == 64 || D == 128) && (DOUT == 64 || DOUT == 128)) {
     const int64_t groups = (n + 63) / 64;
     tgcn_fuse_fwd_lds_kernel<D, DOUT, 32><<<static_cast<unsigned>(groups < 512 ? groups : 512), kFuseThreads, 0, s>>>(
-        T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out);
+        T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out, drop);
     TAGREC_LAUNCH_CHECK();
     return TAGREC_OK;
   }
@@ -415,7 +442,7 @@ int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n
   int64_t blocks = (tiles + 3) / 4;
   if (blocks > 256 * 2) blocks = 256 * 2;
   tgcn_fuse_fwd_kernel<D, DOUT, 32, NS><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
-      T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out);
+      T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out, drop);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
@@ -1546,7 +1573,29 @@ extern "C" int tagrec_tgcn_fuse_fwd_f32(const float* T0, const float* T1, const 
                  "tgcn_fuse_fwd: rows must be 16-byte aligned");
   if (n <= 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL(DD, OO) launch_fuse_fwd<DD, OO>(T0, T1, T2, n, U, q, p, wb, w1, w2, w3, Wf, bf, bw_out, out, s)
+  const FuseDrop drop{0.f, n, n, {nullptr, nullptr, nullptr}, {0, 0, 0}};
+#define CALL(DD, OO) launch_fuse_fwd<DD, OO>(T0, T1, T2, n, U, q, p, wb, w1, w2, w3, Wf, bf, bw_out, out, drop, s)
+  TAGREC_FUSE_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int tagrec_tgcn_fuse_fwd_drop_f32(const float* T0, const float* T1, const float* T2, int64_t n, int D, int Dout,
+                                             int A, int C, int V, const float* U, const float* q, const float* p,
+                                             const float* wb, const float* w1, const float* w2, const float* w3,
+                                             const float* Wf, const float* bf, float drop_p, const uint64_t* seeds3,
+                                             const int64_t* rows0, const int64_t* rows1, const int64_t* rows2, int64_t lo1,
+                                             int64_t lo2, float* bw_out, float* out, void* stream) {
+  TAGREC_REQUIRE(T0 && T1 && T2 && U && q && p && wb && w1 && w2 && w3 && Wf && bf && bw_out && out && seeds3,
+                 "tgcn_fuse_fwd_drop: null pointer");
+  if (A != 32 || C != kBitC || V != kVecC)
+    return fail(TAGREC_E_UNSUPPORTED, "tgcn_fuse: built for dim_atten 32, num_bit_conv 32, num_vec_conv 8");
+  TAGREC_REQUIRE(aligned16(T0) && aligned16(T1) && aligned16(T2) && aligned16(Wf) && aligned16(U) && aligned16(out),
+                 "tgcn_fuse_fwd_drop: rows must be 16-byte aligned");
+  TAGREC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && 0 <= lo1 && lo1 <= lo2 && lo2 <= n, "tgcn_fuse_fwd_drop: bad p or segment bounds");
+  if (n <= 0) return TAGREC_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const FuseDrop drop{drop_p, lo1, lo2, {rows0, rows1, rows2}, {seeds3[0], seeds3[1], seeds3[2]}};
+#define CALL(DD, OO) launch_fuse_fwd<DD, OO>(T0, T1, T2, n, U, q, p, wb, w1, w2, w3, Wf, bf, bw_out, out, drop, s)
   TAGREC_FUSE_DISPATCH(CALL);
 #undef CALL
 }

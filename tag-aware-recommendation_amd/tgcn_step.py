@@ -141,12 +141,22 @@ def attn_bwd_pulls(P, Q, WT, v, Ej, idx, widx, attn, d_out, addQ, addX, w_major=
     return dP, dWT, dv, dQ, dEj
 
 
-def fuse_fwd(t0, t1, t2, dp):
+def fuse_fwd(t0, t1, t2, dp, drop=None):
+    """drop = (p, (seed_user, seed_item, seed_tag), (rows_user, rows_item, rows_tag) node ids or None, lo_item, lo_tag): message
+    dropout of the output in the kernel's epilogue (the mask keyed by node id); the returned `out` is the dropped output."""
     from . import tgcn as TG
     U, q, p, wb, w1, w2, w3, Wf, bf = dp
     n, D = t0.shape
     out = torch.empty(n, Wf.shape[1], dtype=torch.float32, device=t0.device)
     bw = torch.empty(n, 3, dtype=torch.float32, device=t0.device)
+    if drop is not None:
+        pk, seeds, rows, lo1, lo2 = drop
+        seeds3 = (_lib.ctypes.c_uint64 * 3)(*[int(x) for x in seeds])
+        _lib.check(TG._timed("fuse_fwd", _lib.load().tagrec_tgcn_fuse_fwd_drop_f32, _lib.ptr(t0), _lib.ptr(t1), _lib.ptr(t2), n, D,
+                             Wf.shape[1], U.shape[1], wb.shape[0], w1.shape[0], *[_lib.ptr(a) for a in dp], float(pk), seeds3,
+                             _lib.ptr(rows[0]), _lib.ptr(rows[1]), _lib.ptr(rows[2]), int(lo1), int(lo2), _lib.ptr(bw),
+                             _lib.ptr(out), _lib.stream_ptr()), "tgcn_fuse_fwd_drop")
+        return out, bw
     _lib.check(TG._timed("fuse_fwd", _lib.load().tagrec_tgcn_fuse_fwd_f32, _lib.ptr(t0), _lib.ptr(t1), _lib.ptr(t2), n, D,
                          Wf.shape[1], U.shape[1], wb.shape[0], w1.shape[0], *[_lib.ptr(a) for a in dp], _lib.ptr(bw),
                          _lib.ptr(out), _lib.stream_ptr()), "tgcn_fuse_fwd")
@@ -260,16 +270,14 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
                                    out=T3[SLOT[nb]][rng[src]])
             idxs[r] = (idx, widx)
         st.update(attns=attns, idxs=idxs)
-        O_all, BW_all = fuse_fwd(T3[0], T3[1], T3[2], dp)
-        st.update(O=O_all, BW=BW_all)
-        # message dropout of the layer's outputs (tgcn.py:217-219): the library's counter-based mask keyed by NODE id
+        # message dropout of the layer's outputs (tgcn.py:217-219) in the fused kernel's epilogue: the library's counter-based
+        # mask keyed by NODE id; the dropped output is all that is stored ([out' > 0] = mask [out > 0], see the backward)
         pk = drops[li] if drops else 0.0
-        Od_all = O_all
+        drop = None
         if pk > 0:
-            Od_all = torch.empty_like(O_all)
-            for t in TYPES:
-                if m[t]:
-                    H.message_drop(O_all[rng[t]], pk, _drop_seed(seed, li, t), out=Od_all[rng[t]], rows=rows_out[t])
+            drop = (pk, [_drop_seed(seed, li, t) for t in TYPES], [rows_out[t] for t in TYPES], lo["item"], lo["tag"])
+        Od_all, BW_all = fuse_fwd(T3[0], T3[1], T3[2], dp, drop)
+        st.update(O=Od_all, BW=BW_all)
         st["pk"] = pk
         Od = {t: Od_all[rng[t]] for t in TYPES}
         # positions of the batch rows in this layer's output, their normalised rows into the concat buffer
@@ -342,10 +350,8 @@ def step_backward(model, g, state, n_weight):
                 _lib.check(lib.tagrec_rownorm_bwd_f32(_lib.ptr(xr), _lib.ptr(inv), _lib.ptr(d_cat[t][:, st["off"]:]), dtot, 1.0,
                                                       _lib.ptr(dz), 0, xr.shape[0], xr.shape[1], _lib.stream_ptr()), "rownorm_bwd")
                 G_all[rng[t]].index_add_(0, st["extra"][t], dz)          # (the batch rows of a type are distinct)
-        if pk > 0:                                # through the dropout mask (same mask as the forward's)
-            for t in TYPES:
-                if m[t]:
-                    H.message_drop(G_all[rng[t]], pk, _drop_seed(state["seed"], li, t), out=G_all[rng[t]], rows=rows_out[t])
+        if pk > 0:                                # d out = d out' mask / (1 - p), and the kernels' relu mask [out' > 0] holds the mask
+            G_all.mul_(1.0 / (1.0 - pk))
         # ---- fused dense block, the three types in one launch: input gradients + its weight gradients
         r_ = TG._FusedDense._backward_rows(T3[0], T3[1], T3[2], *dp[:8], st["O"], st["BW"], G_all)
         dts_all, dense_g = r_[:3], list(r_[3:12])
