@@ -453,6 +453,31 @@ int tagrec_nbr_gather_i32(const int32_t* idx, const int32_t* widx, const int64_t
 int tagrec_attn_seg_dq_f32(const int32_t* dest_sorted, const int32_t* pair_sorted, int64_t n_entries, int32_t n_dst,
                            const float* comp, const float* v, int A, float* dQ, void* stream);
 
+/* ---- the row plan of a restricted TGCN step (tgcn.py:236-249 reads the top layer at the batch rows only; the tables of
+ *      tgcn.py:194-202 say which rows of the layer below those depend on) ---------------------------------------------
+ * Node types 0, 1, 2 (user, item, tag) of sizes3[] nodes share one flag buffer: segment t starts at byte
+ * tagrec_plan_segment_result(sizes3, t) (t = 3: the total = tagrec_plan_flags_workspace(sizes3) bytes) and holds n_t + 1
+ * slots, slot 0 = the pad id of the neighbour tables, slot v + 1 = row v.
+ *   plan_mark    : clears flags and counts, sets every row of a type with all3[t] != 0, then runs the descriptors
+ *                  i < n_desc (at most 12): idx[i] == NULL -> flag rows[i][j * stride[i]] (j < n_rows[i]) of type
+ *                  dst_type[i]; else flag idx[i][row, 0..k[i]) of type dst_type[i] for row = rows[i][j * stride[i]]
+ *                  (rows[i] == NULL: row = j) < n_src[i].  Ids out of range are skipped and counted in counts[3].
+ *   plan_compact : per type, the flagged rows in ascending order -> rows_out[row_base_t ..) (row_base = 0, n_0, n_0 + n_1;
+ *                  capacity sum of sizes3), their number -> counts[t] (device int64 [4]), and the position map pos_out (int32,
+ *                  the flag buffer's layout): pos_out[slot] = 1 + position of the row in its list, 0 if not flagged.
+ *                  workspace: tagrec_plan_scan_workspace(sizes3) int32.
+ *   plan_lookup  : out[i * out_stride] = pos[rows[i * stride] + 1] - 1 (a row id -> its position in a compact table). */
+int64_t tagrec_plan_flags_workspace(const int64_t* sizes3);
+int64_t tagrec_plan_segment_result(const int64_t* sizes3, int type);
+int64_t tagrec_plan_scan_workspace(const int64_t* sizes3);
+int tagrec_plan_mark_u8(int n_desc, const int32_t* const* idx, const int64_t* const* rows, const int64_t* stride,
+                        const int64_t* n_rows, const int64_t* n_src, const int* k, const int* dst_type, const int* all3,
+                        const int64_t* sizes3, uint8_t* flags, int64_t* counts, void* stream);
+int tagrec_plan_compact_i64(const uint8_t* flags, const int64_t* sizes3, int64_t* rows_out, int32_t* pos_out, int64_t* counts,
+                            int32_t* workspace, int64_t workspace_ints, void* stream);
+int tagrec_plan_lookup_i64(const int32_t* pos, const int64_t* rows, int64_t stride, int64_t n, int64_t* out, int64_t out_stride,
+                           void* stream);
+
 /* ---- TGCN type-level attention + bit/vector convolutions + fusion layer, fused (tgcn.py:78-106) ------------
  * One node type per call.  T0/T1/T2 [n, D]: the (user-side, item-side, tag-side) vectors of each node, in
  * that order.  U [D, A], q [A], p [A]; wb [C, 3] (Conv2d(1,C,(3,1)) weight); w1 [V, D], w2 [V, 2, D],

@@ -77,6 +77,13 @@ _SIGNATURES = {
     "tagrec_attn_pull_dq_f32": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "tagrec_attn_seg_dq_f32": [c_void_p, c_void_p, c_int64, ctypes.c_int32, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "tagrec_nbr_gather_i32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
+    "tagrec_plan_flags_workspace": [c_void_p],
+    "tagrec_plan_segment_result": [c_void_p, c_int],
+    "tagrec_plan_scan_workspace": [c_void_p],
+    "tagrec_plan_mark_u8": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p],
+    "tagrec_plan_compact_i64": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "tagrec_plan_lookup_i64": [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p],
     "tagrec_inv_filter_workspace": [c_int64],
     "tagrec_inv_filter_i32": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_int32, c_int64, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],

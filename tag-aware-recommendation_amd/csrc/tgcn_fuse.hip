@@ -199,7 +199,7 @@ __device__ __forceinline__ int vec_feature(int g, int c) {
 }
 
 // ---- forward -----------------------------------------------------------------------------------
-template <int D, int DOUT, int A, int NS>
+template <int D, int DOUT, int A, int NS, bool DROP = false>
 __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_fwd_kernel(
     const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, int64_t n,
     const float* __restrict__ U, const float* __restrict__ qv, const float* __restrict__ pv,
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_fwd_kernel(
       for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
         for (int v = 0; v < 4; ++v) o[v * OB + ob] = fmaxf(acc[s][ob][v] + bf[q * OS + v * OB + ob], 0.f);
-      fuse_drop<OS, DOUT>(drop, node[s], q, o);
+      if constexpr (DROP) fuse_drop<OS, DOUT>(drop, node[s], q, o);
       float* dst = out + node[s] * DOUT + q * OS;
 #pragma unroll
       for (int i = 0; i < OS; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
@@ -307,7 +307,9 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_fwd_kernel(
 //   (q = 0,1 or q = 2,3) fall on disjoint banks; with Dout = 64 they already do.
 constexpr int kEC = 8;
 
-template <int D, int DOUT, int A>
+// DROP: message dropout in the epilogue -- a separate instantiation, so that the p = 0 kernel keeps its register allocation
+// (with the mask code compiled in it grew from 232 to 252 VGPRs and ran 4-8 % slower)
+template <int D, int DOUT, int A, bool DROP = false>
 __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_fwd_lds_kernel(
     const float* __restrict__ T0, const float* __restrict__ T1, const float* __restrict__ T2, int64_t n,
     const float* __restrict__ U, const float* __restrict__ qv, const float* __restrict__ pv,
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_fwd_lds_kernel(
       for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
         for (int v = 0; v < 4; ++v) o[v * OB + ob] = fmaxf(acc[ob][v] + bf[q * OS + v * OB + ob], 0.f);
-      fuse_drop<OS, DOUT>(drop, node, q, o);
+      if constexpr (DROP) fuse_drop<OS, DOUT>(drop, node, q, o);
       float* dst = out + node * DOUT + q * OS;
 #pragma unroll
       for (int i = 0; i < OS; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
@@ -432,8 +434,13 @@ int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n
                     const float* bf, float* bw_out, float* out, const FuseDrop& drop, hipStream_t s) {
   if constexpr ((D == 64 || D == 128) && (DOUT == 64 || DOUT == 128)) {
     const int64_t groups = (n + 63) / 64;
-    tgcn_fuse_fwd_lds_kernel<D, DOUT, 32><<<static_cast<unsigned>(groups < 512 ? groups : 512), kFuseThreads, 0, s>>>(
-        T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out, drop);
+    const unsigned grid = static_cast<unsigned>(groups < 512 ? groups : 512);
+    if (drop.p > 0.f)
+      tgcn_fuse_fwd_lds_kernel<D, DOUT, 32, true><<<grid, kFuseThreads, 0, s>>>(T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out,
+                                                                              out, drop);
+    else
+      tgcn_fuse_fwd_lds_kernel<D, DOUT, 32, false><<<grid, kFuseThreads, 0, s>>>(T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out,
+                                                                               out, drop);
     TAGREC_LAUNCH_CHECK();
     return TAGREC_OK;
   }
@@ -441,8 +448,12 @@ int launch_fuse_fwd(const float* T0, const float* T1, const float* T2, int64_t n
   const int64_t tiles = (n + 16 * NS - 1) / (16 * NS);
   int64_t blocks = (tiles + 3) / 4;
   if (blocks > 256 * 2) blocks = 256 * 2;
-  tgcn_fuse_fwd_kernel<D, DOUT, 32, NS><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
-      T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out, drop);
+  if (drop.p > 0.f)
+    tgcn_fuse_fwd_kernel<D, DOUT, 32, NS, true><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
+        T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out, drop);
+  else
+    tgcn_fuse_fwd_kernel<D, DOUT, 32, NS, false><<<static_cast<unsigned>(blocks), kFuseThreads, 0, s>>>(
+        T0, T1, T2, n, U, qv, pv, wb, w1, w2, w3, Wf, bf, bw_out, out, drop);
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
