@@ -26,6 +26,7 @@ import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from . import _lib, help as H
+from . import plan as PL
 from . import tgcn_step as TS
 from .config import CFG as _GLOBAL_CFG
 from .graph import Graph
@@ -633,6 +634,7 @@ class TGCN(nn.Module):
         n_dst = [self.num_item, self.num_tag, self.num_user, self.num_tag, self.num_user, self.num_item]
         self.inv = [InverseTable(self.nbr[r][0], n_dst[r]) for r in range(6)] if self.pull_backward else None
         self._eval_cache = None
+        self._row_plan, self._need_pos = None, None
 
     def _config(self, config):
         self.dim_latent = config["dim_latent"]
@@ -704,33 +706,31 @@ class TGCN(nn.Module):
     def _needed_rows(self, batch):
         """need[l][t]: the rows of layer l's output (l = 1..L; type t) that the loss of `batch` depends on -- the batch
         rows at the top, plus, one layer down, their k sampled neighbours under every relation -- or None once a type
-        needs more than half of its rows (then all of them are computed)."""
+        needs more than half of its rows (then all of them are computed).  Built by csrc/plan.hip (two launches and one
+        host read per level); `self._need_pos[l][t]` is the matching position map (int32 [n + 1]: 1 + position of row v at
+        slot v + 1, 0 elsewhere) the compact tables of the step are numbered by."""
         sizes = {"user": self.num_user, "item": self.num_item, "tag": self.num_tag}
+        if self._row_plan is None:
+            self._row_plan = PL.RowPlan(sizes, self.device)
+        plan = self._row_plan
         L = len(self.layer)
-        top = {"user": torch.unique(batch[:, 0]), "item": torch.unique(batch[:, 1:]),
-               "tag": torch.empty(0, dtype=torch.int64, device=self.device)}
-        need = [None] * (L + 1)
-        need[L] = top
+        B, p0 = batch.shape[0], batch.data_ptr()
+        need, pos = [None] * (L + 1), [None] * (L + 1)
+        need[L], pos[L] = plan.level([(None, p0, 3, B, 0, "user"), (None, p0 + 8, 3, B, 0, "item"), (None, p0 + 16, 3, B, 0, "item")])
         for l in range(L, 1, -1):
             cur = need[l]
-            masks = {}
-            for t, n in sizes.items():                               # slot 0 absorbs the pad index of the tables
-                m = torch.zeros(n + 1, dtype=torch.bool, device=self.device)
-                if cur[t] is None:
-                    m[1:] = True
-                elif cur[t].numel():
-                    m[cur[t] + 1] = True
-                masks[t] = m
+            descs = [(None, cur[t], 1, cur[t].numel(), 0, t) for t in sizes if cur[t] is not None and cur[t].numel()]
             for r, (src, nb) in enumerate(self._RELATIONS):
                 if cur[src] is None:
-                    masks[nb][self.nbr[r][0].long().flatten()] = True
+                    descs.append((self.nbr[r][0], None, 1, sizes[src], sizes[src], nb))
                 elif cur[src].numel():
-                    masks[nb][self.nbr[r][0].index_select(0, cur[src]).long().flatten()] = True
-            nxt = {}
+                    descs.append((self.nbr[r][0], cur[src], 1, cur[src].numel(), sizes[src], nb))
+            rows, ps = plan.level(descs, all_types=[t for t in sizes if cur[t] is None])
             for t, n in sizes.items():
-                rows = torch.nonzero(masks[t][1:]).flatten()
-                nxt[t] = None if rows.numel() * 2 > n else rows
-            need[l - 1] = nxt
+                if rows[t].numel() * 2 > n:
+                    rows[t], ps[t] = None, None
+            need[l - 1], pos[l - 1] = rows, ps
+        self._need_pos = pos
         return need
 
     def _forward_rows(self, batch):
@@ -762,19 +762,22 @@ class TGCN(nn.Module):
                 if self.training and p > 0:
                     o = torch.nn.functional.dropout(o, p=p, training=True)
                 nxt[t] = o
-                pos_out[t] = None
-                if rows_out[t] is not None:
-                    pos_out[t] = torch.zeros(sizes[t] + 1, dtype=torch.int32, device=self.device)
-                    pos_out[t][rows_out[t] + 1] = torch.arange(1, rows_out[t].numel() + 1, dtype=torch.int32, device=self.device)
-            extra = {t: (top[t] if rows_out[t] is None else pos_out[t].index_select(0, top[t] + 1).long() - 1) for t in cat}
+                pos_out[t] = self._need_pos[i + 1][t] if rows_out[t] is not None else None
+            extra = {t: (top[t] if rows_out[t] is None else PL.lookup(pos_out[t], top[t])) for t in cat}
             emb, rows_in, pos_in = nxt, rows_out, pos_out
         for t in cat:
             ot = emb[t].index_select(0, extra[t])
             cat[t].append(H.normalize_rows(ot) if ot.shape[0] else ot)
-        trip = torch.stack([torch.searchsorted(top["user"], batch[:, 0].contiguous()),
-                            torch.searchsorted(top["item"], batch[:, 1].contiguous()),
-                            torch.searchsorted(top["item"], batch[:, 2].contiguous())], dim=1)
-        return torch.cat(cat["user"], dim=1), torch.cat(cat["item"], dim=1), trip
+        return torch.cat(cat["user"], dim=1), torch.cat(cat["item"], dim=1), self._batch_positions(batch)
+
+    def _batch_positions(self, batch):
+        """The batch renumbered into the tables of its distinct users / items (the top level of the last `_needed_rows`)."""
+        B, p0 = batch.shape[0], batch.data_ptr()
+        trip = torch.empty(B, 3, dtype=torch.int64, device=batch.device)
+        top_pos = self._need_pos[len(self.layer)]
+        for c, t in enumerate(("user", "item", "item")):
+            PL.lookup(top_pos[t], p0 + 8 * c, stride=3, n=B, out=trip.data_ptr() + 8 * c, out_stride=3)
+        return trip
 
     def loss(self, batch_data):
         batch_data = batch_data.to(self.device, torch.int64).contiguous()

@@ -22,7 +22,7 @@ Same loss and gradients as the all-rows pass (`TGCN.forward()` + triplet loss + 
 """
 import torch
 
-from . import _lib, help as H, proj as PJ
+from . import _lib, help as H, plan as PL, proj as PJ
 
 TYPES = ("user", "item", "tag")
 RELATIONS = (("user", "item"), ("user", "tag"), ("item", "user"), ("item", "tag"), ("tag", "user"), ("tag", "item"))
@@ -195,6 +195,7 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
     dev = batch.device
     lib = _lib.load()
     need = model._needed_rows(batch)
+    need_pos = model._need_pos
     sizes = {"user": model.num_user, "item": model.num_item, "tag": model.num_tag}
     L = len(layers_ps)
     ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])
@@ -234,7 +235,7 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
                 sel[t] = None
                 Xs[t].copy_(X[t])
             else:
-                sel[t] = rows_out[t] if rows_in[t] is None else pos_in[t].index_select(0, rows_out[t] + 1).long() - 1
+                sel[t] = rows_out[t] if rows_in[t] is None else PL.lookup(pos_in[t], rows_out[t])
                 if m[t]:
                     torch.index_select(X[t], 0, sel[t], out=Xs[t])
             if own:
@@ -281,15 +282,11 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
         st["pk"] = pk
         Od = {t: Od_all[rng[t]] for t in TYPES}
         # positions of the batch rows in this layer's output, their normalised rows into the concat buffer
-        pos_out, extra = {}, {}
-        for t in TYPES:
-            pos_out[t] = None
-            if rows_out[t] is not None:
-                pos_out[t] = torch.zeros(sizes[t] + 1, dtype=torch.int32, device=dev)
-                pos_out[t][rows_out[t] + 1] = torch.arange(1, rows_out[t].numel() + 1, dtype=torch.int32, device=dev)
+        extra = {}
+        pos_out = {t: (need_pos[li + 1][t] if rows_out[t] is not None else None) for t in TYPES}
         norm_saved = {}
         for t in cat:
-            extra[t] = top[t] if rows_out[t] is None else pos_out[t].index_select(0, top[t] + 1).long() - 1
+            extra[t] = top[t] if rows_out[t] is None else PL.lookup(pos_out[t], top[t])
             xr = Od[t].index_select(0, extra[t])
             inv = torch.empty(n_top[t], dtype=torch.float32, device=dev)
             if n_top[t]:
@@ -301,9 +298,7 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
         off += d_out
         X, rows_in, pos_in = Od, rows_out, pos_out
     B = batch.shape[0]
-    trip = torch.stack([torch.searchsorted(top["user"], batch[:, 0].contiguous()),
-                        torch.searchsorted(top["item"], batch[:, 1].contiguous()),
-                        torch.searchsorted(top["item"], batch[:, 2].contiguous())], dim=1).contiguous()
+    trip = model._batch_positions(batch)
     coef = torch.empty(B, dtype=torch.float32, device=dev)
     partials = torch.empty(2 * ((B + 3) // 4), dtype=torch.float32, device=dev)
     res = torch.empty(2, dtype=torch.float32, device=dev)
@@ -369,9 +364,13 @@ def step_backward(model, g, state, n_weight):
         have_x = {t: False for t in TYPES}        # dx[t] holds something yet?
         accQ = {t: None for t in TYPES}
         dP = {}
-        dW1 = {t: torch.zeros_like(att[t][0]) for t in TYPES}
-        db = {t: torch.zeros_like(att[t][2]) for t in TYPES}
-        dv = {t: torch.zeros_like(att[t][3]) for t in TYPES}
+        zs = [att[t][i] for i in (0, 2, 3) for t in TYPES]                 # dW1, db, dv of the three types: one zero fill
+        zflat = torch.zeros(sum(z.numel() for z in zs), dtype=torch.float32, device=dev)
+        zv, zo = [], 0
+        for z in zs:
+            zv.append(zflat[zo:zo + z.numel()].view(z.shape))
+            zo += z.numel()
+        dW1, db, dv = ({t: zv[3 * i + j] for j, t in enumerate(TYPES)} for i in range(3))
         dWTs = {t: None for t in TYPES}
         # ---- neighbour attentions: scatter-form relations first (into zeroed buffers), then the pull-form ones, each adding
         # what has been collected so far in its product's epilogue
@@ -415,7 +414,7 @@ def step_backward(model, g, state, n_weight):
                     dx[nb].copy_(px)
                     have_x[nb] = True
             dWTs[nb] = dWT_r if dWTs[nb] is None else dWTs[nb] + dWT_r
-            dv[nb] = dv[nb] + dv_r.reshape(dv[nb].shape)
+            dv[nb] += dv_r.reshape(dv[nb].shape)
         # ---- projections backward
         own = st["own"]
         dW2s = {}

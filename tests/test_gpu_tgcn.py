@@ -647,3 +647,71 @@ def test_sum_n_and_table_fan_out():
     with torch.no_grad():
         (a, b), (s1,) = TG.fan(x, 2, r1)
         assert a.data_ptr() == x.data_ptr() and torch.equal(s1, x[r1])
+
+
+@pytest.mark.parametrize("sizes,k,B", [((1000, 800, 1500), 5, 64), ((5000, 4096, 8191), 25, 512), ((4095, 1, 3), 3, 7),
+                                       ((70_000, 50_000, 90_000), 25, 512)])
+def test_row_plan_kernels_equal_unique_and_nonzero(sizes, k, B):
+    """csrc/plan.hip (mark + compact + lookup) against the torch formulation it replaces: torch.unique of the batch columns,
+    boolean masks filled through the neighbour tables, torch.nonzero, arange position maps, searchsorted -- including a type
+    whose rows are all needed (`all_types`), segment sizes on and next to the 4096-flag chunk boundary, and pad ids."""
+    from tagrec_amd import plan as PL
+    g = torch.Generator().manual_seed(sum(sizes) + k)
+    names = ("user", "item", "tag")
+    n = dict(zip(names, sizes))
+    rel = (("user", "item"), ("user", "tag"), ("item", "user"), ("item", "tag"), ("tag", "user"), ("tag", "item"))
+    nbr = []
+    for src, nb in rel:                                         # ids 1-based, 0 = pad (a third of the slots)
+        t = torch.randint(0, n[nb] + 1, (n[src], k), generator=g, dtype=torch.int32)
+        t[torch.rand(n[src], k, generator=g) < 0.33] = 0
+        nbr.append(t.to(DEV))
+    batch = torch.stack([torch.randint(0, n["user"], (B,), generator=g), torch.randint(0, n["item"], (B,), generator=g),
+                         torch.randint(0, n["item"], (B,), generator=g)], dim=1).to(DEV)
+    plan = PL.RowPlan(n, torch.device(DEV))
+    p0 = batch.data_ptr()
+    rows, pos = plan.level([(None, p0, 3, B, 0, "user"), (None, p0 + 8, 3, B, 0, "item"), (None, p0 + 16, 3, B, 0, "item")])
+    want = {"user": torch.unique(batch[:, 0]), "item": torch.unique(batch[:, 1:]), "tag": batch.new_empty(0)}
+    for t in names:
+        assert torch.equal(rows[t], want[t]), t
+        ref = torch.zeros(n[t] + 1, dtype=torch.int32, device=DEV)
+        ref[want[t] + 1] = torch.arange(1, want[t].numel() + 1, dtype=torch.int32, device=DEV)
+        assert torch.equal(pos[t], ref), t
+    trip = torch.empty(B, 3, dtype=torch.int64, device=DEV)
+    for c, t in enumerate(("user", "item", "item")):
+        PL.lookup(pos[t], p0 + 8 * c, stride=3, n=B, out=trip.data_ptr() + 8 * c, out_stride=3)
+    assert torch.equal(trip[:, 0], torch.searchsorted(want["user"], batch[:, 0].contiguous()))
+    assert torch.equal(trip[:, 2], torch.searchsorted(want["item"], batch[:, 2].contiguous()))
+    # two levels down; at the second one the users are complete ("all rows")
+    cur = dict(want)
+    for level, all_types in ((0, ()), (1, ("user",))):
+        if "user" in all_types:
+            cur["user"] = None
+        masks = {t: torch.zeros(n[t] + 1, dtype=torch.bool, device=DEV) for t in names}
+        descs = []
+        for t in names:
+            if cur[t] is None:
+                masks[t][1:] = True
+            elif cur[t].numel():
+                masks[t][cur[t] + 1] = True
+                descs.append((None, cur[t], 1, cur[t].numel(), 0, t))
+        for r, (src, nb) in enumerate(rel):
+            if cur[src] is None:
+                masks[nb][nbr[r].long().flatten()] = True
+                descs.append((nbr[r], None, 1, n[src], n[src], nb))
+            elif cur[src].numel():
+                masks[nb][nbr[r].index_select(0, cur[src]).long().flatten()] = True
+                descs.append((nbr[r], cur[src], 1, cur[src].numel(), n[src], nb))
+        rows, pos = plan.level(descs, all_types=all_types)
+        for t in names:
+            w = torch.nonzero(masks[t][1:]).flatten()
+            assert torch.equal(rows[t], w), (level, t)
+            ref = torch.zeros(n[t] + 1, dtype=torch.int32, device=DEV)
+            ref[w + 1] = torch.arange(1, w.numel() + 1, dtype=torch.int32, device=DEV)
+            assert torch.equal(pos[t], ref), (level, t)
+            assert torch.equal(PL.lookup(pos[t], w), torch.arange(w.numel(), device=DEV))
+        cur = {t: rows[t].clone() for t in names}
+    # an id outside the type is reported, not written
+    bad = batch.clone()
+    bad[3, 1] = n["item"]
+    with pytest.raises(IndexError):
+        plan.level([(None, bad.data_ptr() + 8, 3, B, 0, "item")])
