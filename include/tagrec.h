@@ -70,6 +70,12 @@ int tagrec_graph_create_like(tagrec_graph** out, const tagrec_graph* like, int64
 int64_t tagrec_graph_workspace(int64_t nnz);
 int tagrec_graph_create_ws(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr,
                            const int32_t* colidx, const float* vals, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same, without the host read of the long-row counters (a read waits for the stream: the TGCN step builds twelve
+ * inverted tables per step).  The work list is sized by its upper bounds, unused slots are marked and skipped by the
+ * kernels; accepted by the tagrec_spmm_*, tagrec_attn_pull_* entry points, refused by the tagrec_route_* ones. */
+int tagrec_graph_create_ws_deferred(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr,
+                                    const int32_t* colidx, const float* vals, void* workspace, int64_t workspace_bytes,
+                                    void* stream);
 int tagrec_graph_create_like_ws(tagrec_graph** out, const tagrec_graph* like, int64_t n_cols, const int32_t* colidx,
                                 const float* vals, void* workspace, int64_t workspace_bytes);
 int tagrec_graph_destroy(tagrec_graph* g);
@@ -311,6 +317,10 @@ int tagrec_transtag_bwd_f32(const float* Eu, const float* Ei, const float* Et, i
  *   m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
 int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
                     float lr, float b1, float b2, float eps, int64_t step, void* stream);
+/* The same update for n_tensors (small) parameter tensors in one launch per 64 of them: host arrays of device pointers and
+ * element counts (< 2^31 each), one step count for all. */
+int tagrec_adam_multi_f32(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                          const int64_t* n, float lr, float b1, float b2, float eps, int64_t step, void* stream);
 /* The same update with the step counter (int64[1]) and the two step-dependent factors (float[2], scratch) in DEVICE
  * memory: the call advances *step_dev itself, so a HIP graph that captured it replays as successive steps. */
 int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* v, int64_t n,

@@ -29,6 +29,8 @@ _SIGNATURES = {
     "tagrec_graph_workspace": [c_int64],
     "tagrec_graph_create_ws": [POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                c_void_p],
+    "tagrec_graph_create_ws_deferred": [POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                        c_void_p],
     "tagrec_graph_create_like_ws": [POINTER(c_void_p), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64],
     "tagrec_graph_destroy": [c_void_p],
     "tagrec_graph_info": [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
@@ -162,6 +164,7 @@ _SIGNATURES = {
     "tagrec_sum_n_f32": [c_void_p, c_void_p, c_int, c_int64, c_void_p],
     "tagrec_adam_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int64,
                         c_void_p],
+    "tagrec_adam_multi_f32": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_void_p],
     "tagrec_adam_graph_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_void_p, c_void_p, c_void_p],
 }

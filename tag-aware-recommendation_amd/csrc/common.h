@@ -60,16 +60,28 @@ __device__ __forceinline__ void drop4(const DropMask& m, int64_t float4_index, f
 }
 
 
-// torch.optim.Adam's update of four elements, in torch's operation order (_single_tensor_adam): shared by the Adam
-// kernel (rowops.hip) and the last backward hop's fused epilogue (spmm.hip).
+// torch.optim.Adam's update (_single_tensor_adam: exp_avg.lerp_(grad, 1 - b1); exp_avg_sq.mul_(b2).addcmul_(grad, grad,
+// 1 - b2); param.addcdiv_(exp_avg, sqrt(exp_avg_sq) / sqrt(bc2) + eps, -step_size)), shared by the Adam kernels (rowops.hip)
+// and the last backward hop's fused epilogue (spmm.hip).  The roundings are PINNED -- contraction off, the three fused
+// multiply-adds written out -- so that every kernel that applies the update gives the same bits whatever surrounds the call
+// (left to the compiler, the vector kernel and a scalar kernel contracted differently).
+__device__ __forceinline__ float adam_update1(float& m, float& v, float p, const float g, float w1, float b2, float w2, float step_size,
+                                              float bc2_sqrt, float eps) {
+#pragma clang fp contract(off)
+  m = fmaf(w1, g - m, m);
+  v = fmaf(w2 * g, g, v * b2);
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  return fmaf(-step_size, m / denom, p);
+}
 typedef float adam_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ adam_f4 adam_update(adam_f4& mi, adam_f4& vi, adam_f4 pi, const adam_f4 gi, float w1, float b2, float w2,
                                                float step_size, float bc2_sqrt, float eps) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    mi[c] = mi[c] + w1 * (gi[c] - mi[c]);             /* exp_avg.lerp_(grad, 1-b1)            */
-    vi[c] = vi[c] * b2 + (w2 * gi[c]) * gi[c];        /* mul_(b2).addcmul_(grad, grad, 1-b2)  */
-    pi[c] = pi[c] - step_size * (mi[c] / (sqrtf(vi[c]) / bc2_sqrt + eps));
+    float m = mi[c], v = vi[c];
+    pi[c] = adam_update1(m, v, pi[c], gi[c], w1, b2, w2, step_size, bc2_sqrt, eps);
+    mi[c] = m;
+    vi[c] = v;
   }
   return pi;
 }

@@ -19,6 +19,7 @@ struct tagrec_graph {
   bool owns_long;             // false: long_rows / long_base / chunk_desc belong to the graph this one was created like,
                               // or live in a caller-provided workspace
   bool owns_slab;             // false: the slab lives in a caller-provided workspace
+  bool deferred = false;      // n_long / n_chunks are upper bounds, unused slots of the work list hold -1 (no host read at creation)
 };
 
 namespace tagrec {

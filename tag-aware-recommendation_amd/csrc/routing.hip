@@ -467,6 +467,7 @@ int k_dispatch(int K, const char* who, F&& f) {
 }
 
 int long_view(const tagrec_graph* g, int width, LongView* lv) {
+  TAGREC_REQUIRE(!g->deferred, "routing kernels need a handle created with a host read (tagrec_graph_create / _ws)");
   *lv = LongView{g->long_rows, g->chunk_desc, g->n_chunks, nullptr, 0};
   if (g->n_long > 0) {
     int rc = ensure_slab(g, width);
@@ -576,6 +577,7 @@ extern "C" int tagrec_route_score_rows_f32(const tagrec_graph* g, const float* H
   TAGREC_REQUIRE(g && H && T, "route_score: null pointer");
   TAGREC_REQUIRE(g->nnz == 0 || logits, "route_score: null logits");
   TAGREC_REQUIRE(aligned16(H) && aligned16(T), "route_score: rows must be 16-byte aligned");
+  TAGREC_REQUIRE(!g->deferred, "route_score: needs a handle created with a host read (tagrec_graph_create / _ws)");
   if (g->n_rows == 0 || g->nnz == 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return route_dispatch(D, K, "route_score", [&](auto lc, auto kc) {

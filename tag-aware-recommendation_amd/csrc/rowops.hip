@@ -472,12 +472,10 @@ __global__ __launch_bounds__(kThreads) void adam_tail_kernel(float* __restrict__
   if (coef) { step_size = coef[0]; bc2_sqrt = coef[1]; }
   const int64_t i = start + static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= n) return;
-  const float gi = g[i];
-  const float mi = m[i] + w1 * (gi - m[i]);
-  const float vi = v[i] * b2 + (w2 * gi) * gi;
+  float mi = m[i], vi = v[i];
+  p[i] = adam_update1(mi, vi, p[i], g[i], w1, b2, w2, step_size, bc2_sqrt, eps);
   m[i] = mi;
   v[i] = vi;
-  p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
 }
 
 // out = mask(seed) * x / (1 - p), the mask of common.h's DropMask (x may alias out)
@@ -723,6 +721,70 @@ extern "C" int tagrec_adam_f32(float* p, const float* g, float* m, float* v, int
   const double bc2 = 1.0 - pow(static_cast<double>(b2), static_cast<double>(step));
   return launch_adam(p, g, m, v, n, b1, b2, eps, static_cast<float>(static_cast<double>(lr) / bc1),
                      static_cast<float>(sqrt(bc2)), nullptr, static_cast<hipStream_t>(stream));
+}
+
+// Many small parameter tensors in ONE launch (a TGCN layer has 21; one launch each costs more in launch latency than in
+// work, and the burst lets the GPU catch up with the host at the end of every step).  Scalar loads / stores: the tensors
+// are small and need not be 16-byte aligned.
+namespace {
+constexpr int kAdamMulti = 64;
+struct AdamMultiArgs {
+  float* p[kAdamMulti];
+  const float* g[kAdamMulti];
+  float* m[kAdamMulti];
+  float* v[kAdamMulti];
+  int n[kAdamMulti];
+};
+__global__ __launch_bounds__(kThreads) void adam_multi_kernel(AdamMultiArgs a, float w1, float b2, float w2, float step_size, float bc2_sqrt,
+                                                              float eps) {
+  const int t = blockIdx.y;
+  const int n = a.n[t];
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  // four consecutive elements per thread through adam_update (common.h): the arithmetic -- and its contraction into FMAs --
+  // is the vector kernel's and the fused epilogue's, so the three ways of applying an update agree bit for bit
+  for (int i = (blockIdx.x * kThreads + threadIdx.x) * 4; i < n; i += gridDim.x * kThreads * 4) {
+    adam_f4 gi = {0.f, 0.f, 0.f, 0.f}, mi = gi, vi = gi, pi = gi;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (i + c < n) { gi[c] = g[i + c]; mi[c] = m[i + c]; vi[c] = v[i + c]; pi[c] = p[i + c]; }
+    const adam_f4 qi = adam_update(mi, vi, pi, gi, w1, b2, w2, step_size, bc2_sqrt, eps);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (i + c < n) { m[i + c] = mi[c]; v[i + c] = vi[c]; p[i + c] = qi[c]; }
+  }
+}
+}  // namespace
+
+extern "C" int tagrec_adam_multi_f32(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                     const int64_t* n, float lr, float b1, float b2, float eps, int64_t step, void* stream) {
+  TAGREC_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (p && g && m && v && n)), "adam_multi: null pointer");
+  TAGREC_REQUIRE(step >= 1, "adam_multi: bad step");
+  const double bc1 = 1.0 - pow(static_cast<double>(b1), static_cast<double>(step));
+  const double bc2 = 1.0 - pow(static_cast<double>(b2), static_cast<double>(step));
+  const float step_size = static_cast<float>(static_cast<double>(lr) / bc1), bc2_sqrt = static_cast<float>(sqrt(bc2));
+  const float w1 = static_cast<float>(1.0 - static_cast<double>(b1)), w2 = static_cast<float>(1.0 - static_cast<double>(b2));
+  for (int t0 = 0; t0 < n_tensors; t0 += kAdamMulti) {
+    AdamMultiArgs a;
+    const int cnt = n_tensors - t0 < kAdamMulti ? n_tensors - t0 : kAdamMulti;
+    int64_t most = 0;
+    for (int i = 0; i < cnt; ++i) {
+      TAGREC_REQUIRE(n[t0 + i] >= 0 && n[t0 + i] < (1ll << 31), "adam_multi: tensor sizes must fit int32 (use tagrec_adam_f32 for tables)");
+      TAGREC_REQUIRE(n[t0 + i] == 0 || (p[t0 + i] && g[t0 + i] && m[t0 + i] && v[t0 + i]), "adam_multi: null tensor");
+      a.p[i] = p[t0 + i]; a.g[i] = g[t0 + i]; a.m[i] = m[t0 + i]; a.v[i] = v[t0 + i];
+      a.n[i] = static_cast<int>(n[t0 + i]);
+      if (n[t0 + i] > most) most = n[t0 + i];
+    }
+    if (most == 0) continue;
+    int64_t bx = (most + 4 * kThreads - 1) / (4 * kThreads);
+    if (bx > 1024) bx = 1024;
+    adam_multi_kernel<<<dim3(static_cast<unsigned>(bx), static_cast<unsigned>(cnt)), kThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        a, w1, b2, w2, step_size, bc2_sqrt, eps);
+    TAGREC_LAUNCH_CHECK();
+  }
+  return TAGREC_OK;
 }
 
 extern "C" int tagrec_adam_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
     const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (c >= lv.n_chunks) return;
     const int2 d = lv.chunk_desc[c];
+    if (d.x < 0) return;                    // unused slot of a handle created without a host read
     const int64_t r = lv.long_rows[d.x];
     if (MASKED && !e.row_mask[r]) return;
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_finish_kernel(Gra
   const int64_t li = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
   if (li >= n_long) return;
   const int64_t r = long_rows[li];
+  if (r < 0) return;                        // unused slot of a handle created without a host read
   if (MASKED && !e.row_mask[r]) return;
   const int64_t deg = g.rowptr[r + 1] - g.rowptr[r];
   const int nc = static_cast<int>((deg + kChunk - 1) / kChunk);
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void attn_pull_da_kernel(Gr
     const int64_t chunk = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (chunk >= lv.n_chunks) return;
     const int2 d = lv.chunk_desc[chunk];
+    if (d.x < 0) return;
     const int64_t r = lv.long_rows[d.x];
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
@@ -689,6 +692,7 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void attn_pull_dq_kernel(Gr
     const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (c >= lv.n_chunks) return;
     const int2 d = lv.chunk_desc[c];
+    if (d.x < 0) return;                    // unused slot of a handle created without a host read
     const int64_t r = lv.long_rows[d.x];
     const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
     const int64_t row_end = g.rowptr[r + 1];
@@ -877,6 +881,51 @@ extern "C" int tagrec_graph_create_ws(tagrec_graph** out, int64_t n_rows, int64_
       return fail(TAGREC_E_INVALID, "graph_create_ws: row pointer inconsistent with nnz (more long rows than nnz allows)");
     }
     g->slab_floats = static_cast<size_t>(kSlabWidth) * g->n_chunks;
+  }
+  *out = g;
+  return TAGREC_OK;
+}
+
+// The same handle WITHOUT the host read of the two counters (a read drains the launch queue: the TGCN step builds twelve
+// inverted tables per step).  The work list is sized by its upper bounds and its unused slots hold -1, which the chunk /
+// finish waves of every kernel in this file skip.
+extern "C" int tagrec_graph_create_ws_deferred(tagrec_graph** out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* rowptr,
+                                               const int32_t* colidx, const float* vals, void* workspace, int64_t workspace_bytes,
+                                               void* stream) {
+  TAGREC_REQUIRE(out != nullptr && rowptr != nullptr, "graph_create_ws_deferred: null pointer");
+  TAGREC_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_rows < (1ll << 31) && n_cols < (1ll << 31), "graph_create_ws_deferred: bad size");
+  TAGREC_REQUIRE(nnz == 0 || (colidx != nullptr && vals != nullptr), "graph_create_ws_deferred: colidx/vals null with nnz > 0");
+  const WsLayout w = ws_layout(nnz);
+  TAGREC_REQUIRE(workspace != nullptr && workspace_bytes >= static_cast<int64_t>(w.total) &&
+                     (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
+                 "graph_create_ws_deferred: workspace smaller than tagrec_graph_workspace(nnz) or not 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  tagrec_graph* g = new (std::nothrow) tagrec_graph();
+  if (!g) return fail(TAGREC_E_NOMEM, "graph_create_ws_deferred: host allocation failed");
+  *g = tagrec_graph{n_rows, n_cols, nnz, rowptr, colidx, vals, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, false, false};
+  if (n_rows > 0) {
+    char* base = static_cast<char*>(workspace);
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(base + w.off_counters);
+    auto bail = [&](const char* what, hipError_t e2) {
+      delete g;
+      return fail(TAGREC_E_HIP, std::string("graph_create_ws_deferred: ") + what + ": " + hipGetErrorString(e2));
+    };
+    hipError_t err;
+    g->long_rows = reinterpret_cast<int32_t*>(base + w.off_long_rows);
+    g->long_base = reinterpret_cast<int32_t*>(base + w.off_long_base);
+    g->chunk_desc = reinterpret_cast<int2*>(base + w.off_chunk_desc);
+    g->slab = reinterpret_cast<float*>(base + w.off_slab);
+    if ((err = hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), s)) != hipSuccess) return bail("memset", err);
+    if ((err = hipMemsetAsync(g->long_rows, 0xFF, sizeof(int32_t) * w.n_long_max, s)) != hipSuccess) return bail("memset", err);
+    if ((err = hipMemsetAsync(g->chunk_desc, 0xFF, sizeof(int2) * w.n_chunks_max, s)) != hipSuccess) return bail("memset", err);
+    const int threads = 256;
+    const unsigned blocks = static_cast<unsigned>((n_rows + threads - 1) / threads);
+    fill_long_kernel<<<blocks, threads, 0, s>>>(rowptr, n_rows, counters, g->long_rows, g->long_base, g->chunk_desc);
+    if ((err = hipGetLastError()) != hipSuccess) return bail("fill_long launch", err);
+    g->n_long = w.n_long_max;            // upper bounds (ws_layout): the slots past the real counts stay -1
+    g->n_chunks = w.n_chunks_max;
+    g->slab_floats = static_cast<size_t>(kSlabWidth) * g->n_chunks;
+    g->deferred = true;
   }
   *out = g;
   return TAGREC_OK;

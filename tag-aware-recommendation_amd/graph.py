@@ -196,9 +196,11 @@ class Graph:
     """Device CSR + the library handle built on it.  Owns the three tensors (the
     library only borrows them) and, lazily, the transposed graph for backward."""
 
-    def __init__(self, rowptr, col, val, shape, symmetric=False, workspace=False):
+    def __init__(self, rowptr, col, val, shape, symmetric=False, workspace=False, deferred=False):
         """workspace=True: the handle's device metadata (long-row work list, partial-sum slab) lives in a torch tensor
-        owned by this object instead of hipMalloc'ed memory -- for matrices created and dropped inside a training step."""
+        owned by this object instead of hipMalloc'ed memory -- for matrices created and dropped inside a training step.
+        deferred=True (with workspace): no host read of the long-row counters at creation (the launch queue is not drained);
+        the work list is sized by its upper bounds."""
         self.rowptr = _lib.require_gpu_tensor(rowptr, torch.int64, "rowptr")
         self.col = _lib.require_gpu_tensor(col, torch.int32, "col")
         self.val = _lib.require_gpu_tensor(val, torch.float32, "val")
@@ -217,9 +219,9 @@ class Graph:
                 self._ws = torch.empty(nb + 256, dtype=torch.uint8, device=self.val.device)
                 off = (-self._ws.data_ptr()) % 256
                 self._ws_ptr = self._ws.data_ptr() + off
-                _lib.check(lib.tagrec_graph_create_ws(_lib.ctypes.byref(self._h), self.shape[0], self.shape[1], col.numel(),
-                                                      _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.c_void_p(self._ws_ptr),
-                                                      nb, _lib.stream_ptr()), "graph_create_ws")
+                create = lib.tagrec_graph_create_ws_deferred if deferred else lib.tagrec_graph_create_ws
+                _lib.check(create(_lib.ctypes.byref(self._h), self.shape[0], self.shape[1], col.numel(), _lib.ptr(rowptr), _lib.ptr(col),
+                                  _lib.ptr(val), _lib.c_void_p(self._ws_ptr), nb, _lib.stream_ptr()), "graph_create_ws")
             else:
                 _lib.check(lib.tagrec_graph_create(_lib.ctypes.byref(self._h), self.shape[0], self.shape[1], col.numel(),
                                                    _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.stream_ptr()),

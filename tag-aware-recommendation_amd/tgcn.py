@@ -577,7 +577,8 @@ def neighbor_tables_device(rel, neighbor_k, seed=0):
 
 
 timing = None     # set to {} to record (start, end) events around the attention kernels (bench.py)
-_PULL_MIN_ROWS = 8192          # compact attention backward: pull form from this many active rows on
+_PULL_MIN_ROWS = 32768         # compact attention backward: pull form from this many active rows on (measured at C4: the
+                               # scatter form of a 20 k-row relation is one launch, the pull form ~35 small ones)
 _SPARSE_MIN_ROWS = 16384      # below this a backward call is too small for dropping its zero-gradient rows to pay
 
 

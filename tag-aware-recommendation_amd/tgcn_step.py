@@ -24,6 +24,17 @@ import torch
 
 from . import _lib, help as H, plan as PL, proj as PJ
 
+MARKS = None      # tools/c4_host_timeline.py sets a list: (name, host time, HIP event) at a few points of the step
+
+
+def _mark(name):
+    if MARKS is not None:
+        import time
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        MARKS.append((name, time.perf_counter(), ev))
+
+
 TYPES = ("user", "item", "tag")
 RELATIONS = (("user", "item"), ("user", "tag"), ("item", "user"), ("item", "tag"), ("tag", "user"), ("tag", "item"))
 OTHERS = {"user": ("item", "tag"), "item": ("user", "tag"), "tag": ("user", "item")}
@@ -116,7 +127,7 @@ def attn_bwd_pulls(P, Q, WT, v, Ej, idx, widx, attn, d_out, addQ, addX, w_major=
         _lib.check(lib.tagrec_attn_invert_fill(_lib.ptr(order), _lib.ptr(attn), k, n * k, _lib.ptr(pair), _lib.ptr(src), _lib.ptr(val),
                                                _lib.stream_ptr()), "attn_invert_fill")
     rowptr = torch.searchsorted(skey, torch.arange(n_dst + 1, dtype=torch.int32, device=dev))
-    inv = Graph(rowptr, src, val, (n_dst, n), workspace=True)
+    inv = Graph(rowptr, src, val, (n_dst, n), workspace=True, deferred=True)
     da = torch.empty(n * k, dtype=torch.float32, device=dev)
     dEj = out if out is not None else torch.empty(n_dst, D, dtype=torch.float32, device=dev)      # (may alias addX: element-wise)
     _lib.check(TG._timed("attn_pull_da", lib.tagrec_attn_pull_da_f32, inv.handle, _lib.ptr(pair), _lib.ptr(d_out), _lib.ptr(Ej),
@@ -194,8 +205,10 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
     Returns (res [2], state)."""
     dev = batch.device
     lib = _lib.load()
+    _mark("step start")
     need = model._needed_rows(batch)
     need_pos = model._need_pos
+    _mark("plan done")
     sizes = {"user": model.num_user, "item": model.num_item, "tag": model.num_tag}
     L = len(layers_ps)
     ewp = torch.cat([ew.new_zeros(1, ew.shape[1]), ew])
@@ -295,6 +308,7 @@ def step_forward(model, batch, embs, ew, layers_ps, training_drop):
             norm_saved[t] = (xr, inv)
         st.update(extra=extra, norm=norm_saved, off=off, pos_out=pos_out)
         saved.append(st)
+        _mark(f"forward layer {li} queued")
         off += d_out
         X, rows_in, pos_in = Od, rows_out, pos_out
     B = batch.shape[0]
@@ -473,6 +487,7 @@ def step_backward(model, g, state, n_weight):
         lg += [x.reshape(s_) for x, s_ in zip(dense_g, shapes)]
         layer_grads[li] = lg
         saved[li] = None
+        _mark(f"backward layer {li} queued")
         if li > 0:
             G_all = dX_all
         else:

@@ -22,6 +22,8 @@ class Adam:
     HIP pass per parameter tensor.  Same zero_grad()/step() protocol, so it drops into
     `epoch_training` where the reference passes a torch optimizer."""
 
+    MULTI_MAX_NUMEL = 1 << 22         # tensors up to this size share one launch (tagrec_adam_multi_f32); 0: one launch each
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         """capturable=True keeps every parameter's step counter in device memory and advances it inside the
         update (tagrec_adam_graph_f32), so `step()` can be captured in a HIP graph and replayed (`GraphedStep`)."""
@@ -93,6 +95,7 @@ class Adam:
     def step(self):
         lib = _lib.load()
         self.step_count += 1
+        small = {}                                        # step count -> [(p, g, m, v)] of the tensors updated in one launch
         for p in self.params:
             if id(p) in self._fused_done:             # updated inside backward(): only the step counter moves here
                 self._fused_done.discard(id(p))
@@ -111,6 +114,9 @@ class Adam:
                     st["t_dev"] = torch.zeros(1, dtype=torch.int64, device=p.device)
                     st["coef"] = torch.zeros(2, dtype=torch.float32, device=p.device)
             st["t"] += 1
+            if not self.capturable and p.numel() <= self.MULTI_MAX_NUMEL:
+                small.setdefault(st["t"], []).append((p.data, g, st["m"], st["v"]))       # one launch for all of them, below
+                continue
             if self.capturable:
                 _lib.check(lib.tagrec_adam_graph_f32(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
                                                      p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
@@ -120,6 +126,14 @@ class Adam:
                 _lib.check(lib.tagrec_adam_f32(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
                                                p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, st["t"],
                                                _lib.stream_ptr()), "adam")
+        # the small tensors (a TGCN layer has 21): launches of up to 64 tensors each instead of a burst of tiny launches, during
+        # which the GPU caught up with the host at the end of every step
+        for t, group in small.items():
+            k = len(group)
+            arr = [(_lib.ctypes.c_void_p * k)(*[x[i].data_ptr() for x in group]) for i in range(4)]
+            n = (_lib.ctypes.c_int64 * k)(*[x[0].numel() for x in group])
+            _lib.check(lib.tagrec_adam_multi_f32(k, arr[0], arr[1], arr[2], arr[3], n, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                 t, _lib.stream_ptr()), "adam_multi")
 
     def prepare_state(self):
         """Allocate every parameter's state now (graph capture must not meet a first-use allocation whose zero fill

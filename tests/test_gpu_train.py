@@ -560,3 +560,33 @@ def test_restricted_step_reads_no_unwritten_row_model_level_poison(name, monkeyp
         if name == "ngcf":
             from tagrec_amd import ngcf as NG
             NG.RESTRICT_FORWARD = True
+
+
+def test_multi_tensor_adam_is_bit_identical_to_one_launch_per_tensor():
+    """`Adam.step` updates the small tensors of a model in one launch (tagrec_adam_multi_f32); three steps on tensors of odd
+    sizes / alignments against the same optimizer with one launch per tensor (MULTI_MAX_NUMEL = 0), bit for bit, and against
+    torch.optim.Adam within float rounding."""
+    g = torch.Generator().manual_seed(4)
+    shapes = [(1,), (3,), (17, 5), (128, 32), (4129,), (64, 64), (2, 3, 7), (1000, 130)] + [(33,)] * 70
+    base = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(3)]
+
+    def run(kind):
+        ps = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+        if kind == "torch":
+            opt = torch.optim.Adam(ps, lr=0.01)
+        else:
+            opt = T.Adam(ps, lr=0.01)
+            if kind == "single":
+                opt.MULTI_MAX_NUMEL = 0
+        for gs in grads:
+            for p, gg in zip(ps, gs):
+                p.grad = gg.to(DEV)
+            ps[5].grad = ps[5].grad if gs is not grads[1] else None         # a tensor that skips a step keeps its own count
+            opt.step()
+        return [p.detach().clone() for p in ps]
+
+    multi, single, ref = run("multi"), run("single"), run("torch")
+    for a, b, c in zip(multi, single, ref):
+        assert torch.equal(a, b)
+        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=2e-6, atol=1e-7)

@@ -40,6 +40,10 @@ def main():
     hi = ends[which]
     lo = ends[which - 1]
     step = [(s, e, n) for s, e, n in rows if s > lo and e <= hi]
+    if os.environ.get("WINDOW"):                       # WINDOW=a,b (ms from the start of the step): only that part of it
+        a, b = (float(x) * 1e6 for x in os.environ["WINDOW"].split(","))
+        step = [(s, e, n) for s, e, n in step if s - lo >= a and s - lo < b]
+        lo, hi = lo + int(a), lo + int(b)
     agg = defaultdict(lambda: [0, 0, 0])
     busy, gap, prev = 0, 0, lo
     for s, e, n in step:
@@ -52,6 +56,30 @@ def main():
             gap += s - prev
         prev = max(prev, e)
     wall = hi - lo
+    # the largest idle gaps and the kernels on either side (GAPS=n lists n of them)
+    n_gaps = int(os.environ.get("GAPS", "0"))
+    if n_gaps:
+        gaps, prev_e, prev_n = [], lo, "(previous step)"
+        for s, e, n in step:
+            if s > prev_e:
+                gaps.append((s - prev_e, (prev_e - lo) / 1e6, prev_n[:70], n[:70]))
+            if e > prev_e:
+                prev_e, prev_n = e, n
+        hist = [sum(g[0] for g in gaps if lo_ <= g[0] < hi_) / 1e6 for lo_, hi_ in ((0, 5e3), (5e3, 2e4), (2e4, 1e5), (1e5, 1e12))]
+        print(f"# idle by gap length: <5 us {hist[0]:.2f} ms, 5-20 us {hist[1]:.2f} ms, 20-100 us {hist[2]:.2f} ms, >100 us {hist[3]:.2f} ms")
+        for g in sorted(gaps, reverse=True)[:n_gaps]:
+            print(f"# gap {g[0] / 1e3:8.1f} us at +{g[1]:7.2f} ms  after {g[2]}  before {g[3]}")
+    # TIMELINE=us: every kernel of the step at least that long, in launch order, with the number of shorter launches between
+    tl = float(os.environ.get("TIMELINE", "0"))
+    if tl:
+        small_n, small_t = 0, 0
+        for s, e, n in step:
+            if e - s >= tl * 1e3:
+                print(f"# +{(s - lo) / 1e6:7.2f} ms  {(e - s) / 1e3:8.1f} us  {n[:90]}   (after {small_n} shorter launches, {small_t / 1e3:.0f} us)")
+                small_n, small_t = 0, 0
+            else:
+                small_n += 1
+                small_t += e - s
     out = [("kernel", "total_ms", "calls", "mean_us", "max_us", "share")]
     for n, (t, c, m) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         out.append((n[:110], f"{t / 1e6:.3f}", c, f"{t / c / 1e3:.1f}", f"{m / 1e3:.1f}", f"{t / wall:.3f}"))
