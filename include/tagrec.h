@@ -445,7 +445,8 @@ int tagrec_attn_keys_i32(const int32_t* idx, int64_t n, int32_t n_dst, int32_t* 
  *   it (0 = not computed; int32 [n_src + 1]); the entries of those rows are compacted IN ORDER into skey (destination,
  *   renumbered through pos_dst[d + 1] - 1 when pos_dst != NULL), pair (= position k + slot), src (= position) and val
  *   (= attn[pair]); skey[total .. capacity) is set to n_dst ("no entry").  capacity >= the number of listed entries (rows k
- *   is always enough).  workspace: tagrec_inv_filter_workspace(n_entries) int32; workspace[blocks] = the total on return. */
+ *   is always enough).  workspace: tagrec_inv_filter_workspace(n_entries) int32, 8-byte aligned; workspace[1] = the total on
+ *   return.  One pass over the static list (ticketed blocks, chained scan of their counts); k <= 64. */
 int64_t tagrec_inv_filter_workspace(int64_t n_entries);
 int tagrec_inv_filter_i32(const int32_t* perm_sorted, const int32_t* dest_sorted, int64_t n_entries, int k,
                           const int32_t* pos_src, const int32_t* pos_dst, const float* attn, int32_t n_dst,

@@ -402,94 +402,82 @@ __global__ __launch_bounds__(256) void nbr_gather_kernel(const int32_t* __restri
 // ---- a step's inverted table WITHOUT a sort -----------------------------------------------------------------------------
 // The neighbour tables are static, so every relation's pair list sorted by destination is built ONCE (model start-up).  A
 // step needs the sub-list of the pairs whose SOURCE row is among the rows it computes: an order-preserving compaction of
-// the static list -- count per block, scan of the block counts, scatter -- which writes, already in destination order,
-// everything the pulls read: destination (renumbered into the step's compact table), pair id p' = row' k + slot (row' =
-// the source row's position in the step's row subset), source row, attention weight.  Replaces one radix sort per
-// relation, layer and step (the library's kernels) plus the passes that followed it.
+// the static list which writes, already in destination order, everything the pulls read: destination (renumbered into the
+// step's compact table), pair id p' = row' k + slot (row' = the source row's position in the step's row subset), source
+// row, attention weight.  Replaces one radix sort per relation, layer and step (the library's kernels) plus the passes that
+// followed it.
+// ONE pass over the static list (it is 25 M entries per relation at C4, read twice by a count / scan / scatter scheme):
+// blocks take tickets, publish their count and look back over their predecessors' published counts / prefixes (a
+// "chained scan"); a block waits only for blocks with smaller tickets, which are running by construction (they drew
+// their ticket earlier) and publish their own count BEFORE they look back, so every wait ends.
 constexpr int kFiltThreads = 256;
 constexpr int kFiltPerThread = 16;
 constexpr int kFiltBlock = kFiltThreads * kFiltPerThread;     // static entries per block
+constexpr unsigned long long kFiltValueMask = (1ull << 62) - 1;    // status word: flag (0 empty, 1 count, 2 prefix) << 62 | value
 
-__device__ __forceinline__ bool filt_active(const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_src, int k, int64_t e,
-                                            int64_t n_entries, int& row_c, int& slot) {
+// p / k for 0 <= p < 2^31, 1 <= k <= 64 without a division: magic = floor(2^40 / k) + 1 (error term p (magic k - 2^40) < 2^40)
+__device__ __forceinline__ int div_magic(int p, unsigned long long magic) {
+  return static_cast<int>((static_cast<unsigned long long>(static_cast<unsigned>(p)) * magic) >> 40);
+}
+
+__device__ __forceinline__ bool filt_active(const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_src, int k,
+                                            unsigned long long magic, int64_t e, int64_t n_entries, int& row_c, int& slot) {
   if (e >= n_entries) return false;
   const int p = perm[e];
-  const int v = p / k;
+  const int v = div_magic(p, magic);
   slot = p - v * k;
   row_c = pos_src[v + 1] - 1;                                  // -1: the source row is not computed this step
   return row_c >= 0;
 }
 
-__global__ __launch_bounds__(kFiltThreads) void inv_filter_count_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_src,
-                                                                         int k, int64_t n_entries, int32_t* __restrict__ block_counts) {
-  __shared__ int wave_cnt[kFiltThreads / 64];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kFiltBlock;
-  int cnt = 0;
-#pragma unroll 4
-  for (int i = 0; i < kFiltPerThread; ++i) {
-    int rc, sl;
-    cnt += filt_active(perm, pos_src, k, base + i * kFiltThreads + threadIdx.x, n_entries, rc, sl) ? 1 : 0;
-  }
-  for (int m = 1; m < 64; m <<= 1) cnt += __shfl_xor(cnt, m);
-  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int w = 0; w < kFiltThreads / 64; ++w) t += wave_cnt[w];
-    block_counts[blockIdx.x] = t;
-  }
-}
-
-// exclusive scan of the block counts in place (one block; n_blocks is a few thousand); total -> block_counts[n_blocks]
-__global__ __launch_bounds__(1024) void inv_filter_scan_kernel(int32_t* __restrict__ block_counts, int n_blocks) {
-  __shared__ int sh[1024];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n_blocks; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < n_blocks ? block_counts[i] : 0;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                 // Hillis-Steele inclusive scan
-      const int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-      __syncthreads();
-      sh[threadIdx.x] += t;
-      __syncthreads();
-    }
-    const int incl = sh[threadIdx.x];
-    if (i < n_blocks) block_counts[i] = carry + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) block_counts[n_blocks] = carry;
-}
-
-__global__ __launch_bounds__(kFiltThreads) void inv_filter_scatter_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ dest,
-                                                                           const int32_t* __restrict__ pos_src, const int32_t* __restrict__ pos_dst,
-                                                                           const float* __restrict__ attn, int k, int64_t n_entries,
-                                                                           const int32_t* __restrict__ block_offsets, int n_blocks,
-                                                                           int32_t n_dst, int64_t capacity, int32_t* __restrict__ skey,
-                                                                           int32_t* __restrict__ pair, int32_t* __restrict__ src,
-                                                                           float* __restrict__ val) {
+__global__ __launch_bounds__(kFiltThreads) void inv_filter_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ dest,
+                                                                   const int32_t* __restrict__ pos_src, const int32_t* __restrict__ pos_dst,
+                                                                   const float* __restrict__ attn, int k, unsigned long long magic,
+                                                                   int64_t n_entries, int32_t* __restrict__ ws, int n_blocks,
+                                                                   int32_t* __restrict__ skey, int32_t* __restrict__ pair,
+                                                                   int32_t* __restrict__ src, float* __restrict__ val) {
   // wave w of the block takes the contiguous quarter [w 1024, (w + 1) 1024) of the block's entries, 64 per pass: the 16
-  // ballot masks and the active lanes' (row, slot) stay in registers, ONE barrier orders the four waves' totals
+  // ballot masks and the active lanes' (row, slot) stay in registers
   __shared__ int wave_tot[kFiltThreads / 64];
+  __shared__ int bid_s;
+  __shared__ long long excl_s;
+  unsigned* ticket = reinterpret_cast<unsigned*>(ws);
+  unsigned long long* status = reinterpret_cast<unsigned long long*>(ws + 4);
+  if (threadIdx.x == 0) bid_s = static_cast<int>(atomicAdd(ticket, 1u));
+  __syncthreads();
+  const int bid = bid_s;                                        // the block's place in the list = the order it started in
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t wbase = static_cast<int64_t>(blockIdx.x) * kFiltBlock + static_cast<int64_t>(wave) * (64 * kFiltPerThread);
+  const int64_t wbase = static_cast<int64_t>(bid) * kFiltBlock + static_cast<int64_t>(wave) * (64 * kFiltPerThread);
   int rcs[kFiltPerThread], sls[kFiltPerThread];
   unsigned long long masks[kFiltPerThread];
   int tot = 0;
 #pragma unroll
   for (int i = 0; i < kFiltPerThread; ++i) {
-    const bool act = filt_active(perm, pos_src, k, wbase + i * 64 + lane, n_entries, rcs[i], sls[i]);
+    const bool act = filt_active(perm, pos_src, k, magic, wbase + i * 64 + lane, n_entries, rcs[i], sls[i]);
     masks[i] = __ballot(act);
     tot += __popcll(masks[i]);
   }
   if (lane == 0) wave_tot[wave] = tot;
   __syncthreads();
-  int64_t out = block_offsets[blockIdx.x];
+  if (threadIdx.x == 0) {
+    unsigned long long mine = 0;
+    for (int w = 0; w < kFiltThreads / 64; ++w) mine += static_cast<unsigned long long>(wave_tot[w]);
+    unsigned long long excl = 0;
+    if (bid > 0) {
+      __hip_atomic_store(&status[bid], (1ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // count first, then look back
+      for (int j = bid - 1;; --j) {                            // ends at the latest at block 0, which publishes a prefix at once
+        unsigned long long st;
+        while (((st = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+        excl += st & kFiltValueMask;
+        if ((st >> 62) == 2) break;
+      }
+    }
+    __hip_atomic_store(&status[bid], (2ull << 62) | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    excl_s = static_cast<long long>(excl);
+    if (bid == n_blocks - 1) ws[1] = static_cast<int32_t>(excl + mine);        // the number of listed entries
+  }
+  __syncthreads();
+  int64_t out = excl_s;
   for (int w = 0; w < wave; ++w) out += wave_tot[w];
 #pragma unroll
   for (int i = 0; i < kFiltPerThread; ++i) {
@@ -506,13 +494,6 @@ __global__ __launch_bounds__(kFiltThreads) void inv_filter_scatter_kernel(const 
     }
     out += __popcll(m);
   }
-  // the unused tail of the destination keys marks "no entry" (>= n_dst), as the pads behind a sorted list did
-  const int64_t total = block_offsets[n_blocks];
-  const int64_t tail = capacity - total;
-  const int64_t per = (tail + gridDim.x - 1) / gridDim.x;
-  const int64_t t0 = total + static_cast<int64_t>(blockIdx.x) * per;
-  const int64_t t1 = (t0 + per < capacity) ? t0 + per : capacity;
-  for (int64_t j = t0 + threadIdx.x; j < t1; j += kFiltThreads) skey[j] = n_dst;
 }
 
 // sort keys of an on-the-spot table inversion: destination row of every (node, slot) pair, pads behind the last row
@@ -705,28 +686,28 @@ extern "C" int tagrec_nbr_gather_i32(const int32_t* idx, const int32_t* widx, co
   return TAGREC_OK;
 }
 
-extern "C" int64_t tagrec_inv_filter_workspace(int64_t n_entries) { return (n_entries + kFiltBlock - 1) / kFiltBlock + 2; }
+extern "C" int64_t tagrec_inv_filter_workspace(int64_t n_entries) { return 2 * ((n_entries + kFiltBlock - 1) / kFiltBlock + 1) + 4; }
 
 extern "C" int tagrec_inv_filter_i32(const int32_t* perm_sorted, const int32_t* dest_sorted, int64_t n_entries, int k,
                                      const int32_t* pos_src, const int32_t* pos_dst, const float* attn, int32_t n_dst,
                                      int64_t capacity, int32_t* skey, int32_t* pair, int32_t* src, float* val,
                                      int32_t* workspace, int64_t workspace_ints, void* stream) {
-  TAGREC_REQUIRE(n_entries >= 0 && k >= 1 && capacity >= 0, "inv_filter: bad size");
+  TAGREC_REQUIRE(n_entries >= 0 && n_entries < (1ll << 31) && k >= 1 && k <= 64 && capacity >= 0, "inv_filter: bad size (k <= 64, < 2^31 entries)");
   TAGREC_REQUIRE(pos_src && workspace && (capacity == 0 || (skey && pair && src && val)) && (n_entries == 0 || (perm_sorted && dest_sorted && attn)),
                  "inv_filter: null pointer");
   TAGREC_REQUIRE(workspace_ints >= tagrec_inv_filter_workspace(n_entries), "inv_filter: workspace too small");
+  TAGREC_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "inv_filter: workspace must be 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_blocks = static_cast<int>((n_entries + kFiltBlock - 1) / kFiltBlock);
+  // ticket, total and the blocks' status words start at zero; the keys start as "no entry" (>= n_dst: what the pads behind
+  // a sorted list were), the listed ones are written over the head
+  TAGREC_HIP(hipMemsetAsync(workspace, 0, sizeof(int32_t) * static_cast<size_t>(tagrec_inv_filter_workspace(n_entries)), s));
+  if (capacity > 0) TAGREC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(skey), n_dst, static_cast<size_t>(capacity), s));
   if (n_blocks > 0) {
-    inv_filter_count_kernel<<<n_blocks, kFiltThreads, 0, s>>>(perm_sorted, pos_src, k, n_entries, workspace);
+    const unsigned long long magic = (1ull << 40) / static_cast<unsigned long long>(k) + 1;
+    inv_filter_kernel<<<n_blocks, kFiltThreads, 0, s>>>(perm_sorted, dest_sorted, pos_src, pos_dst, attn, k, magic, n_entries, workspace,
+                                                        n_blocks, skey, pair, src, val);
     TAGREC_LAUNCH_CHECK();
   }
-  inv_filter_scan_kernel<<<1, 1024, 0, s>>>(workspace, n_blocks);
-  TAGREC_LAUNCH_CHECK();
-  // at least one block so that the tail of skey is marked even when nothing is listed
-  const int grid = n_blocks > 0 ? n_blocks : 1;
-  inv_filter_scatter_kernel<<<grid, kFiltThreads, 0, s>>>(perm_sorted, dest_sorted, pos_src, pos_dst, attn, k, n_entries, workspace,
-                                                          n_blocks, n_dst, capacity, skey, pair, src, val);
-  TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }
