@@ -254,6 +254,8 @@ def bench_tgcn(args, ceilings=None):
     torch.manual_seed(cfg["seed"])
     model = T.TGCN(ds, config=cfg)
     opt = T.Adam(model.parameters(), lr=cfg["lr"])
+    if not args.no_fused_adam:            # the node tables' update in the epilogue of the last product that lands on them
+        opt.fuse_into(model)
     prod = T.BPR_training_data(ds, config=cfg, seed=2020)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
@@ -338,6 +340,7 @@ def bench_tgcn(args, ceilings=None):
                      "transtag_step_ms": t_tt * 1e3,
                      "attention_ms_per_step": sum(sum(v) for kk, v in ms.items() if kk.startswith("attn")) / K,
                      "pruned_forward": bool(model.prune_forward),
+                     "fused_adam": bool(not args.no_fused_adam),
                      "fused_dense_ms_per_step": sum(sum(ms.get(kk, [])) for kk in ("fuse_fwd", "fuse_bwd", "fuse_wf")) / K,
                      "note": "the step is one hand-derived autograd node (tgcn_step.py): fused MFMA dense block (csrc/tgcn_fuse.hip: fwd, "
                              "bwd-data, bwd-Wf; the three node types of a layer in one launch), neighbour attention (csrc/tgcn.hip) with the "

@@ -555,6 +555,14 @@ int tagrec_tgcn_fuse_wf_f32(const float* T0, const float* T1, const float* T2, c
 int tagrec_tall_mm_f32(const float* X1, const float* X2, const int64_t* sel, int64_t n, int K, int NO, const float* W1,
                        const float* W2, int64_t w_sk, int64_t w_sc, int w_split, const float* b1, const float* b2,
                        float* Y1, float* Y2, int accumulate, void* stream);
+/*   tall_mm_adam : the gradient G = G_in + X W (X [n, K], W(k, c) = W[k * w_sk + c * w_sc], G_in [n, NO] or NULL) of the
+ *             embedding table p [n, NO] is not stored: torch.optim.Adam's update of p, exp_avg m and exp_avg_sq v (the arithmetic
+ *             of tagrec_adam_f32, step = the number of this update) is applied in the product's epilogue -- the last term of
+ *             a TGCN table's gradient is dQ W_2^T (tgcn.py:20-37), so the optimizer never reads a gradient tensor
+ *             (training/basic_train.py:21,25). */
+int tagrec_tall_mm_adam_f32(const float* X, int64_t n, int K, int NO, const float* W, int64_t w_sk, int64_t w_sc,
+                            const float* G_in, float* p, float* m, float* v, float lr, float b1, float b2, float eps,
+                            int64_t step, void* stream);
 int64_t tagrec_tall_wgrad_workspace(int KI, int NO);
 int tagrec_tall_wgrad_f32(const float* X, const float* dY1, const float* dY2, int64_t n, int KI, int NO, float* dW,
                           float* db1, float* db2, int acc_w, int acc_b, float* workspace, int64_t workspace_floats, void* stream);

@@ -147,6 +147,8 @@ _SIGNATURES = {
                                   c_float, c_float, c_float, c_float, c_int64, c_int, c_void_p],
     "tagrec_tall_mm_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "tagrec_tall_mm_adam_f32": [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_float, c_float, c_float, c_float, c_int64, c_void_p],
     "tagrec_tall_wgrad_workspace": [c_int, c_int],
     "tagrec_tall_wgrad_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_int64, c_void_p],

@@ -50,6 +50,8 @@ struct TallArgs {
   const float* b1; const float* b2;      // bias (b2: the columns >= NO/2 when the output is split)
   float* Y1; float* Y2;                  // Y2 != nullptr: columns [NO/2, NO) go there (both with row stride NO/2)
   int accumulate;
+  AdamRow adam;                          // adam.p != nullptr: the result (+ what Y1 holds, with `accumulate`) is the GRADIENT of the
+                                         // table adam.p [n, NO]; its Adam update is applied here and nothing is stored to Y1
 };
 
 template <int K, int NO>
@@ -117,7 +119,18 @@ __global__ __launch_bounds__(kProjThreads) void tall_mm_kernel(TallArgs a, Small
         else dst = a.Y1 + row * NO + c;
         pj4 o = acc[cb];
         if (a.accumulate) o += old[cb];
-        *reinterpret_cast<pj4*>(dst) = o;
+        if (a.adam.p) {                     // (wave-uniform) the table's update in place of the gradient store
+          const int64_t off = row * NO + c;
+          adam_f4 mi = *reinterpret_cast<const adam_f4*>(a.adam.m + off), vi = *reinterpret_cast<const adam_f4*>(a.adam.v + off);
+          const adam_f4 pi = *reinterpret_cast<const adam_f4*>(a.adam.p + off);
+          const adam_f4 qi = adam_update(mi, vi, pi, adam_f4{o[0], o[1], o[2], o[3]}, a.adam.w1, a.adam.b2, a.adam.w2, a.adam.step_size,
+                                         a.adam.bc2_sqrt, a.adam.eps);
+          *reinterpret_cast<adam_f4*>(a.adam.m + off) = mi;
+          *reinterpret_cast<adam_f4*>(a.adam.v + off) = vi;
+          *reinterpret_cast<adam_f4*>(a.adam.p + off) = qi;
+        } else {
+          *reinterpret_cast<pj4*>(dst) = o;
+        }
       }
     }
   }
@@ -313,12 +326,38 @@ extern "C" int tagrec_tall_mm_f32(const float* X1, const float* X2, const int64_
   TAGREC_REQUIRE(!b2 || Y2, "tall_mm: a second bias goes with a second output");
   if (n == 0) return TAGREC_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const TallArgs a{X1, X2, sel, b1, b2, Y1, Y2, accumulate};
+  const TallArgs a{X1, X2, sel, b1, b2, Y1, Y2, accumulate, AdamRow{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
   const SmallMat w{W1, W2, w_sk, w_sc, w_split};
 #define CALL(KK, NN) launch_tall<KK, NN>(a, w, n, s)
   PROJ_DISPATCH(K, NO, CALL);
 #undef CALL
   return fail(TAGREC_E_UNSUPPORTED, "tall_mm: shape not covered");
+}
+
+// dX = G_in + X W with the Adam update of the table `p` [n, NO] in the epilogue: the gradient row is consumed where its last
+// term is formed (no gradient tensor is written, the optimizer does not read one).  G_in may be NULL (no earlier terms).
+extern "C" int tagrec_tall_mm_adam_f32(const float* X, int64_t n, int K, int NO, const float* W, int64_t w_sk, int64_t w_sc,
+                                       const float* G_in, float* p, float* m, float* v, float lr, float b1, float b2, float eps,
+                                       int64_t step, void* stream) {
+  TAGREC_REQUIRE(n >= 0 && dim_ok(K) && dim_ok(NO), "tall_mm_adam: K and NO must be 16, 32, 64 or 128");
+  TAGREC_REQUIRE(step >= 1, "tall_mm_adam: bad step");
+  if (n == 0) return TAGREC_OK;
+  TAGREC_REQUIRE(X && W && p && m && v, "tall_mm_adam: null pointer");
+  TAGREC_REQUIRE(aligned16(X) && aligned16(p) && aligned16(m) && aligned16(v) && (!G_in || aligned16(G_in)),
+                 "tall_mm_adam: 16-byte aligned rows expected");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // same host arithmetic as tagrec_adam_f32 (torch's _single_tensor_adam: python floats = doubles)
+  const double bc1 = 1.0 - pow(static_cast<double>(b1), static_cast<double>(step));
+  const double bc2 = 1.0 - pow(static_cast<double>(b2), static_cast<double>(step));
+  AdamRow ad{p, m, v, static_cast<float>(1.0 - static_cast<double>(b1)), b2, static_cast<float>(1.0 - static_cast<double>(b2)),
+             static_cast<float>(static_cast<double>(lr) / bc1), static_cast<float>(sqrt(bc2)), eps};
+  // Y1 = G_in: read as the accumulate source, never written (the Adam branch stores to p / m / v instead)
+  const TallArgs a{X, nullptr, nullptr, nullptr, nullptr, const_cast<float*>(G_in), nullptr, G_in ? 1 : 0, ad};
+  const SmallMat w{W, nullptr, w_sk, w_sc, 0};
+#define CALL(KK, NN) launch_tall<KK, NN>(a, w, n, s)
+  PROJ_DISPATCH(K, NO, CALL);
+#undef CALL
+  return fail(TAGREC_E_UNSUPPORTED, "tall_mm_adam: shape not covered");
 }
 
 extern "C" int64_t tagrec_tall_wgrad_workspace(int KI, int NO) {

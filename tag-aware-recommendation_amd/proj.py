@@ -34,6 +34,16 @@ def tall_mm(X1, W1, out, *, X2=None, sel=None, W2=None, w_split=0, transposed=Fa
     return out
 
 
+def tall_mm_adam(X, W, g_in, param, m, v, lr, betas, eps, step, *, transposed=False):
+    """The Adam update of the table `param` [n, NO] for the gradient g_in + X W (g_in may be None), applied in the product's
+    epilogue: no gradient tensor is written (include/tagrec.h, tagrec_tall_mm_adam_f32)."""
+    n, K = X.shape
+    NO = param.shape[1]
+    _, sk, sc = _strides(W, transposed)
+    _lib.check(_lib.load().tagrec_tall_mm_adam_f32(_lib.ptr(X), n, K, NO, _lib.ptr(W), sk, sc, _lib.ptr(g_in), _lib.ptr(param), _lib.ptr(m),
+                                                   _lib.ptr(v), lr, betas[0], betas[1], eps, step, _lib.stream_ptr()), "tall_mm_adam")
+
+
 def tall_wgrad(X, dY1, dY2=None, *, dW=None, db1=None, db2=None, acc_w=False, acc_b=False):
     """dW [KI, NO] (+)= X^T [dY1 | dY2]; db1 / db2 (+)= column sums.  Returns dW (allocated when None and not accumulating)."""
     lib = _lib.load()

@@ -636,6 +636,7 @@ class TGCN(nn.Module):
         self.inv = [InverseTable(self.nbr[r][0], n_dst[r]) for r in range(6)] if self.pull_backward else None
         self._eval_cache = None
         self._row_plan, self._need_pos = None, None
+        self._fused_opt = None
 
     def _config(self, config):
         self.dim_latent = config["dim_latent"]
@@ -670,6 +671,16 @@ class TGCN(nn.Module):
     def train(self, mode=True):
         self._eval_cache = None
         return super().train(mode)
+
+    def fused_tables(self):
+        """The parameters whose Adam update the restricted step can apply itself (`Adam.fuse_into`): the three node tables."""
+        return [self.embed["user"], self.embed["item"], self.embed["tag"]]
+
+    def set_fused_optimizer(self, opt):
+        """`Adam.fuse_into(model)`: the step node (tgcn_step.py) applies the node tables' Adam update in the epilogue of the
+        product that forms the last term of their gradient (dQ W_2^T of the bottom layer); every other path -- the TransTag
+        phase, the autograd-composed passes -- hands the optimizer gradients as usual.  None switches it off."""
+        self._fused_opt = opt
 
     def _drops(self):
         """(per-layer drop rates, seed of this pass) when message dropout is active (tgcn.py:217-219), else (None, 0): the

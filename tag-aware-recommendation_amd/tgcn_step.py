@@ -338,6 +338,11 @@ def step_backward(model, g, state, n_weight):
                                       _lib.ptr(coef), _lib.ptr(g.contiguous()), 1.0, _lib.ptr(dU), _lib.ptr(dI), _lib.ptr(dU),
                                       _lib.ptr(dI), _lib.stream_ptr()), "bpr_bwd")
     L = len(saved)
+    # Adam.fuse_into(model): the node tables' update rides in the epilogue of the product that forms the last term of their
+    # gradient (bottom layer, dQ W_2^T): no gradient tensor for them, no separate optimizer pass over the tables
+    from .train import fused_optimizer
+    fused_opt = fused_optimizer(model)
+    fused_done = set()
     layer_grads = [None] * L
     d_ewp = None
     G_all = None              # gradient w.r.t. the merged output rows of the layer being processed (written by the layer above)
@@ -432,6 +437,13 @@ def step_backward(model, g, state, n_weight):
         # ---- projections backward
         own = st["own"]
         dW2s = {}
+        if li == 0:                               # the ego slot of the concat at the batch rows (layer 0's "output" is the table)
+            for t in cat:
+                if cat[t].shape[0]:
+                    if not have_x[t]:
+                        dx[t].zero_()
+                        have_x[t] = True
+                    dx[t].index_add_(0, top[t], d_cat[t][:, :dims[0]])
         for t, (n1, n2) in OTHERS.items():
             r1, r2 = RELATIONS.index((t, n1)), RELATIONS.index((t, n2))
             dXs = None
@@ -447,7 +459,28 @@ def step_backward(model, g, state, n_weight):
                         dXs.addmm_(dP[r_i], att[n_][0][:D].t())
                         dW1[n_][:D] += tall_wgrad(Xs[t], dP[r_i])
                         db[n_] += dP[r_i].sum(0, keepdim=True)
-            if accQ[t] is not None:
+            fuse_t = (li == 0 and fused_opt is not None and own and accQ[t] is not None
+                      and X[t].data_ptr() == model.embed[t].data_ptr() and X[t].shape[1] in PJ.DIMS)
+            if fuse_t:
+                # every other term first (the product below is the LAST one), the weight gradient before the table changes
+                dW2s[t] = PJ.tall_wgrad(X[t], accQ[t])
+                if dXs is not None:
+                    if not have_x[t]:
+                        dx[t].zero_()
+                        have_x[t] = True
+                    if sel[t] is None:
+                        dx[t] += dXs
+                    else:
+                        PJ.row_add_at(dx[t], sel[t], dXs)
+                    dXs = None
+                prm = model.embed[t]
+                m_, v_, t_ = fused_opt.fused_state(prm)
+                PJ.tall_mm_adam(accQ[t], att[t][1], dx[t] if have_x[t] else None, prm.data, m_, v_, fused_opt.lr, fused_opt.betas,
+                                fused_opt.eps, t_, transposed=True)
+                fused_opt.fused_commit(prm)
+                fused_done.add(t)
+                have_x[t] = True
+            elif accQ[t] is not None:
                 if own:
                     PJ.tall_mm(accQ[t], att[t][1], dx[t], transposed=True, accumulate=have_x[t])
                     dW2s[t] = PJ.tall_wgrad(X[t], accQ[t])
@@ -492,10 +525,8 @@ def step_backward(model, g, state, n_weight):
             G_all = dX_all
         else:
             d_tables = dx
-    # embedding tables: layer 0's input gradient + the ego slot of the concat at the batch rows
-    for t in cat:
-        if cat[t].shape[0]:
-            d_tables[t].index_add_(0, top[t], d_cat[t][:, :dims[0]])
+    for t in fused_done:                          # updated above: the optimizer gets no gradient for them
+        d_tables[t] = None
     d_weight = d_ewp[1:] if d_ewp is not None else torch.zeros(n_weight, model.dim_weight, device=dev)
     flat = [d_tables["user"], d_tables["item"], d_tables["tag"], d_weight]
     for lg in layer_grads:

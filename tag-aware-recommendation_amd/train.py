@@ -53,10 +53,10 @@ class Adam:
         if self.capturable and not getattr(model, "fused_capturable", False):
             raise _lib.TagrecError("Adam.fuse_into: this model's fused update keeps its step counter on the host (capturable=False)")
         if hasattr(model, "set_fused_optimizer"):
-            table = getattr(model, "table", None)
-            if table is not None and not any(q is table for q in self.params):
-                raise _lib.TagrecError("Adam.fuse_into: the model's table is not one of this optimizer's parameters")
-            if table is not None:
+            for table in _fused_tables(model):
+                if not any(q is table for q in self.params):
+                    raise _lib.TagrecError("Adam.fuse_into: the model's table is not one of this optimizer's parameters")
+            for table in _fused_tables(model):
                 table._tagrec_owner = self
             model.set_fused_optimizer(self)
         return self
@@ -146,6 +146,15 @@ class Adam:
                     st["coef"] = torch.zeros(2, dtype=torch.float32, device=p.device)
 
 
+def _fused_tables(model):
+    """The parameters a model can update inside its own backward pass: `model.fused_tables()` (TGCN: the three node
+    tables) or the single `model.table`."""
+    if hasattr(model, "fused_tables"):
+        return list(model.fused_tables())
+    table = getattr(model, "table", None)
+    return [] if table is None else [table]
+
+
 def fused_optimizer(model):
     """The optimizer whose update of `model.table` runs inside the model's backward pass (`Adam.fuse_into`), or None:
     the fusion is live only while that optimizer is still the newest one built over the table -- a second optimizer
@@ -153,7 +162,8 @@ def fused_optimizer(model):
     opt = getattr(model, "_fused_opt", None)
     if opt is None:
         return None
-    if getattr(getattr(model, "table", None), "_tagrec_owner", None) is not opt:
+    tables = _fused_tables(model)
+    if not tables or any(getattr(t, "_tagrec_owner", None) is not opt for t in tables):
         model._fused_opt = None
         return None
     return opt

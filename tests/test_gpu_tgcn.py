@@ -715,3 +715,57 @@ def test_row_plan_kernels_equal_unique_and_nonzero(sizes, k, B):
     bad[3, 1] = n["item"]
     with pytest.raises(IndexError):
         plan.level([(None, bad.data_ptr() + 8, 3, B, 0, "item")])
+
+
+def test_adam_fused_into_the_step_node_equals_the_separate_optimizer_pass():
+    """`T.Adam(...).fuse_into(model)` on TGCN: the node tables' update rides in the epilogue of the product that forms the
+    last term of their gradient (tagrec_tall_mm_adam_f32); `.grad` of the tables stays None and `step()` only counts.
+    Four steps (BPR phase) + one TransTag step (which hands out gradients as usual) at 200 k nodes against the un-fused
+    optimizer: same losses, the same parameters and Adam state up to the order in which the gradient's terms are added
+    (Adam divides by sqrt(v): an element whose gradient is ~1e-7 may move by a fraction of lr either way)."""
+    ds = T.synth.make_tripartite_device(50_000, 50_000, 100_000, 3_000_000, seed=6, device=DEV)
+    cfg = T.get_config("tgcn", dim_latent=64, dim_layer_list=[64, 64, 64], device=DEV, train_batch=256, neighbor_k=25, reg=1e-4)
+    prod = T.BPR_training_data(ds, config=cfg, seed=5)
+    batches = [prod.all_train_data[i * 256:(i + 1) * 256] for i in range(4)]
+    lr = 0.005
+    runs = []
+    for fuse in (False, True):
+        torch.manual_seed(1)
+        m = T.TGCN(ds, config=cfg)
+        m.train()
+        opt = T.Adam(m.parameters(), lr=lr)
+        if fuse:
+            opt.fuse_into(m)
+        losses = []
+        for b in batches:
+            lossx = m.loss(b)
+            opt.zero_grad()
+            sum(lossx).backward()
+            if fuse:
+                assert all(p.grad is None for p in m.fused_tables()) and m.embed["weight"].grad is not None
+                with pytest.raises(T.TagrecError):                    # a second fused backward before step()
+                    sum(m.loss(b)).backward()
+            opt.step()
+            losses.append([float(v.detach()) for v in lossx])
+        gq = torch.Generator(device=DEV).manual_seed(8)                # quad = (user, tag, positive item, negative item)
+        tt = torch.stack([batches[0][:, 0], torch.randint(0, 100_000, (256,), device=DEV, generator=gq), batches[0][:, 1],
+                          batches[0][:, 2]], dim=1)
+        lt = m.transtag_loss(tt)
+        opt.zero_grad()
+        sum(lt).backward()
+        assert all(p.grad is not None for p in m.fused_tables())
+        opt.step()
+        state = {k: p.detach().clone() for k, p in m.named_parameters()}
+        adam = {k: (opt.state[id(p)]["m"].clone(), opt.state[id(p)]["v"].clone(), opt.state[id(p)]["t"]) for k, p in m.named_parameters()}
+        runs.append((losses, state, adam))
+    (l0, s0, a0), (l1, s1, a1) = runs
+    np.testing.assert_allclose(l1, l0, rtol=2e-5)
+    for k in s0:
+        assert a0[k][2] == a1[k][2] == (5 if k in ("embed.user", "embed.item", "embed.tag") else 4), k   # (TransTag: the tables only)
+        d = (s1[k] - s0[k]).abs()
+        assert float(d.max()) <= 2 * 5 * lr, (k, float(d.max()))
+        if k in ("embed.user", "embed.item", "embed.tag"):             # the fused tensors themselves: element by element
+            assert float((d > 0.02 * lr).float().mean()) < 2e-3, (k, float((d > 0.02 * lr).float().mean()))
+            np.testing.assert_allclose(a1[k][1].cpu().numpy(), a0[k][1].cpu().numpy(), rtol=1e-3, atol=1e-12, err_msg=k)
+        # (the small tensors -- biases whose gradient is a sum that cancels to ~1e-8 -- take steps of +-lr on rounding noise:
+        #  the two runs' tables differ in the last bit after the first step, which is enough to flip such a sign)

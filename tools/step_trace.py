@@ -3,7 +3,7 @@
 
     python3 tools/step_trace.py <dir with *_kernel_trace.csv> [out.csv]
 
-A training step ends with a burst of `adam_kernel` launches (one per parameter tensor), so the trace is cut at the end
+A training step ends with a burst of `adam_kernel` / `adam_multi_kernel` launches, so the trace is cut at the end
 of every burst; the LAST complete window that is preceded by another burst is one steady-state step.  Prints, for that
 step, the time per kernel name (sum, calls, mean, max), the busy time and the idle gaps between kernels."""
 import csv
@@ -25,7 +25,7 @@ def main():
     ends = []
     last = None
     for s, e, n in rows:
-        if "adam_kernel" in n:
+        if "adam_kernel" in n or "adam_multi_kernel" in n:
             if last is not None and s - last > 2_000_000:
                 ends.append(last)
             last = e
