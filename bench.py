@@ -242,6 +242,7 @@ def bench_tgcn(args, ceilings=None):
     Returns the JSON object of the line."""
     import tagrec_amd as T
     from tagrec_amd import tgcn as TG
+    from tagrec_amd.tgcn_step import layer_params as TS_layer_params, _dense_views as TS_dense_views
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     sc = args.scale
@@ -326,6 +327,31 @@ def bench_tgcn(args, ceilings=None):
                                                 "flops of the fusion product 2 n (32 D + 48) D only",
                      "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                      "traffic": None, "ms_all_rows_per_layer": sum(fuse_all) / L}
+    if roof_mfma is not None:
+        # the clock the kernel actually runs at: the 157 TFLOP/s peak is quoted at 2.4 GHz, the chip lowers its clock under
+        # the fp32 matrix load.  A one-wave sampler (tagrec_probe_clock) on a second stream, launched first, spins through
+        # one forward launch on 1 M random rows.
+        try:
+            from tagrec_amd import _lib
+            g_ = torch.Generator(device=dev).manual_seed(0)
+            rnd = lambda *sh: torch.randn(*sh, device=dev, generator=g_) * 0.1
+            tt3 = [rnd(1_000_000, D) for _ in range(3)]
+            lp = TS_dense_views([p_.detach() for p_ in TS_layer_params(model.layer["0"])[12:]])
+            res = torch.zeros(2, dtype=torch.int64, device=dev)
+            side = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                _lib.check(_lib.load().tagrec_probe_clock(6000, _lib.ptr(res), _lib.c_void_p(side.cuda_stream)), "probe_clock")
+            with torch.no_grad():
+                TG._FusedDense.apply(*tt3, *lp, 0)
+            torch.cuda.synchronize()
+            cyc, ticks = res.tolist()
+            mhz = cyc / ticks * 100.0
+            roof_mfma["shader_clock_mhz_under_kernel"] = round(mhz)
+            roof_mfma["frac_at_measured_clock"] = tf / (MFMA_F32_PEAK_TFLOPS * mhz / 2400.0)
+            del tt3
+        except Exception as e:                                   # a diagnostic: never fails the bench line
+            roof_mfma["shader_clock_mhz_under_kernel"] = f"not measured: {e}"
     if roof is not None and ceilings:
         roof["measured_ceilings"] = ceilings
     out = {"metric": f"BPR triplets/sec, TGCN {L}-layer dim{D}, tripartite {nu}/{ni}/{nt} nodes, k={k}",

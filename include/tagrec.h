@@ -587,6 +587,9 @@ int tagrec_probe_read_f32(const float* b, int64_t n, float* out, void* stream);
 int64_t tagrec_probe_gather_out_floats(void);
 int tagrec_probe_gather_rows_f32(const float* table, int64_t n_rows, int D, const int32_t* idx, int64_t n_idx, float* out,
                                  void* stream);
+/* One wavefront spins for spin_us and returns out2 = {shader cycles, 100 MHz ticks}: launched on another stream before a
+ * kernel, it measures the clock that kernel runs at (the peaks of the roofline are quoted at 2.4 GHz). */
+int tagrec_probe_clock(int64_t spin_us, int64_t* out2, void* stream);
 
 #ifdef __cplusplus
 }

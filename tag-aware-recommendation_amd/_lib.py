@@ -159,6 +159,7 @@ _SIGNATURES = {
     "tagrec_probe_triad_f32": [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p],
     "tagrec_probe_read_f32": [c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_probe_gather_out_floats": [],
+    "tagrec_probe_clock": [c_int64, c_void_p, c_void_p],
     "tagrec_probe_gather_rows_f32": [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p],
     "tagrec_adam_advance": [c_void_p, c_void_p, c_float, c_float, c_float, c_void_p],
     "tagrec_spmm_axpy_adam_graph_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,

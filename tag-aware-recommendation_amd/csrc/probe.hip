@@ -61,6 +61,25 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const pf4* __restrict
   out[wave * 64 + lane] = acc;
 }
 
+
+// Shader clock while other work runs: one wavefront reads the shader-cycle counter (s_memtime) and the constant 100 MHz
+// counter (s_memrealtime) at both ends of a timed spin.  Launched on a second stream BEFORE the kernel under study, it
+// shares the chip's clock with it: cycles / ticks x 100 MHz = the frequency the kernel actually ran at (the peaks of
+// MI355X_MICROARCH.md are quoted at 2.4 GHz).  Ends by the wall clock, whatever else happens.
+__global__ void probe_clock_kernel(long long spin_ticks, long long* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64();
+  const long long c0 = clock64();
+  long long t1 = t0;
+  while (t1 - t0 < spin_ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    t1 = wall_clock64();
+  }
+  const long long c1 = clock64();
+  out[0] = c1 - c0;
+  out[1] = t1 - t0;
+}
+
 }  // namespace
 }  // namespace tagrec
 
@@ -111,6 +130,13 @@ extern "C" int tagrec_probe_gather_rows_f32(const float* table, int64_t n_rows, 
     case 256: probe_gather_kernel<64><<<blocks, 256, 0, s>>>(t, idx, n_idx / 64, o); break;
     default: return fail(TAGREC_E_UNSUPPORTED, "probe_gather: D must be 32, 64, 128 or 256");
   }
+  TAGREC_LAUNCH_CHECK();
+  return TAGREC_OK;
+}
+
+extern "C" int tagrec_probe_clock(int64_t spin_us, int64_t* out2, void* stream) {
+  TAGREC_REQUIRE(out2 && spin_us >= 1 && spin_us <= 1000000, "probe_clock: 1 us .. 1 s");
+  probe_clock_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(spin_us * 100, reinterpret_cast<long long*>(out2));
   TAGREC_LAUNCH_CHECK();
   return TAGREC_OK;
 }

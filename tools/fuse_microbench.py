@@ -25,3 +25,25 @@ for k, v in TG.timing.items():
     ms = [a.elapsed_time(b) for a, b in v][1:]
     m = sum(ms) / len(ms)
     print(f"{k}: {m:.2f} ms  ({flop / m / 1e9:.1f} TFLOP/s of the fusion product)")
+
+# the shader clock while each kernel runs: a one-wave sampler on a second stream, launched first (tagrec_probe_clock)
+from tagrec_amd import _lib
+lib = _lib.load()
+side = torch.cuda.Stream()
+for name in ("idle", "fuse_fwd", "fuse_bwd+wf"):
+    res = torch.zeros(2, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        _lib.check(lib.tagrec_probe_clock(6000 if name != "fuse_bwd+wf" else 20000, _lib.ptr(res), _lib.c_void_p(side.cuda_stream)), "probe_clock")
+    if name == "fuse_fwd":
+        with torch.no_grad():
+            TG._FusedDense.apply(*t, *prm, 0)
+    elif name != "idle":
+        out = TG._FusedDense.apply(*t, *prm, 0)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            _lib.check(lib.tagrec_probe_clock(20000, _lib.ptr(res), _lib.c_void_p(side.cuda_stream)), "probe_clock")
+        out.backward(torch.ones_like(out))
+    torch.cuda.synchronize()
+    c, tk = res.tolist()
+    print(f"shader clock during {name}: {c / tk * 100:.0f} MHz  ({tk / 100:.0f} us sampled)")
