@@ -282,6 +282,108 @@ __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_kernel(Graph
   row_epilogue<LPR, EPI>(acc, r, lane, e);
 }
 
+// ---- masked hop with a handful of flagged operand rows: one row per LANE GROUP ------------------------------------------
+// The hop below the top layer of a restricted backward pass visits the rows of a mask (the batch rows' neighbours: ~40 % of
+// the graph at C2) and gathers only FLAGGED operand rows (the <= 3 B batch rows): a row reads its ~50 column ids and flag
+// bytes and finds 0-3 of them flagged.  With one wavefront per row that is three dependent memory latencies per row and
+// nothing to amortise them (0.73 ms for 160 MB of indices at C2).  Here every lane group of LPR lanes walks ITS OWN row
+// (64 / LPR rows per wave): the latencies of 4 rows (D = 64) overlap, the flagged entries of a group are taken in entry
+// order (a fixed order: the result is reproducible), and the epilogue runs per group.  Long rows: chunks first, as in
+// spmm_rows_kernel, folded by spmm_finish_kernel.
+template <int LPR, int EPI>
+__global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_rows_grouped_kernel(GraphView g, const float* __restrict__ X,
+                                                                                    EpiArgs e, LongView lv) {
+  static_assert(EPI == EPI_NORMBWD || EPI == EPI_AXPY, "grouped rows: the two masked backward hops");
+  static_assert(LPR <= 32, "grouped rows: at least two rows per wavefront");
+  constexpr int NPI = kWave / LPR;
+  const int lane = threadIdx.x & (kWave - 1);
+  if (blockIdx.x < lv.chunk_blocks) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (c >= lv.n_chunks) return;
+    const int2 d = lv.chunk_desc[c];
+    if (d.x < 0) return;
+    const int64_t r = lv.long_rows[d.x];
+    if (!e.row_mask[r]) return;
+    const int64_t start = g.rowptr[r] + static_cast<int64_t>(d.y) * kChunk;
+    const int64_t row_end = g.rowptr[r + 1];
+    const int64_t end = (start + kChunk < row_end) ? start + kChunk : row_end;
+    const float4 acc = gather_rows<LPR, true>(g, X, start, end, lane, e.in_flags);
+    if (lane < LPR) reinterpret_cast<float4*>(lv.slab)[c * LPR + lane] = acc;
+    return;
+  }
+  const int q = lane / LPR, c = lane % LPR;
+  const int64_t wv = static_cast<int64_t>(blockIdx.x - lv.chunk_blocks) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t r = wv * NPI + q;
+  bool valid = r < g.n_rows && e.row_mask[r];
+  int64_t start = 0;
+  int len = 0;
+  if (valid) {
+    start = g.rowptr[r];
+    const int64_t deg = g.rowptr[r + 1] - start;
+    if (deg > kLongRow) valid = false;          // chunked above, folded by spmm_finish_kernel
+    else len = static_cast<int>(deg);
+  }
+  int maxlen = len;
+#pragma unroll
+  for (int m = LPR; m < kWave; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m));
+  const float4* __restrict__ Xv = reinterpret_cast<const float4*>(X) + c;
+  float4 acc = f4_zero();
+  for (int base = 0; base < maxlen; base += LPR) {
+    const int n = len - base;                    // entries of this group's row in the batch (may be <= 0)
+    int my_col = 0;
+    float my_val = 0.f;
+    if (c < n) {
+      my_col = ld_stream(g.col + start + base + c);
+      if (e.in_flags[my_col]) my_val = ld_stream(g.val + start + base + c);      // a zero weight marks "row not needed"
+    }
+    const unsigned long long m = __ballot(my_val != 0.f);
+    unsigned gm = static_cast<unsigned>((m >> (q * LPR)) & ((1ull << LPR) - 1ull));   // the group's flagged entries
+    int maxcnt = __popc(gm);
+#pragma unroll
+    for (int mm = LPR; mm < kWave; mm <<= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, mm));
+    for (int t = 0; t < maxcnt; t += 2) {
+      float4 x[2];
+      float v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool ok = gm != 0u;
+        const int bit = ok ? __ffs(static_cast<int>(gm)) - 1 : 0;
+        gm &= gm - 1u;                                                            // (0 stays 0)
+        const int col = __shfl(my_col, q * LPR + bit);
+        const float w = __shfl(my_val, q * LPR + bit);
+        v[u] = ok ? w : 0.f;
+        x[u] = ok ? Xv[static_cast<int64_t>(col) * LPR] : f4_zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) f4_fma(acc, v[u], x[u]);
+    }
+  }
+  if (!valid) return;                            // (whole lane groups leave: the group reductions below stay inside a group)
+  const int64_t off = r * LPR + c;
+  float4 o = acc;
+  if constexpr (EPI == EPI_NORMBWD) {
+    if (!e.b_flags || e.b_flags[r]) {
+      const float4 xr = ld_stream(reinterpret_cast<const float4*>(e.Xraw) + off);
+      float4 dz = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
+      dz.x *= e.s; dz.y *= e.s; dz.z *= e.s; dz.w *= e.s;
+      const float4 gz = normalize_bwd<LPR>(xr, e.inv_norm[r], dz);
+      o = make_float4(acc.x + gz.x, acc.y + gz.y, acc.z + gz.z, acc.w + gz.w);
+    }
+    drop4(e.drop, off, o.x, o.y, o.z, o.w);
+    st_stream(reinterpret_cast<float4*>(e.Y) + off, o);
+    if (e.out_flags) {
+      const float nz = group_sum<LPR>((o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) ? 1.f : 0.f);
+      if (c == 0) e.out_flags[r] = nz != 0.f;
+    }
+  } else {
+    if (!(e.b_flags && !e.b_flags[r])) {
+      const float4 b = ld_stream(reinterpret_cast<const float4*>(e.B) + off);
+      o = make_float4(fmaf(e.s, b.x, acc.x), fmaf(e.s, b.y, acc.y), fmaf(e.s, b.z, acc.z), fmaf(e.s, b.w, acc.w));
+    }
+    st_stream(reinterpret_cast<float4*>(e.Y) + off, o);
+  }
+}
+
 template <int LPR, int EPI, bool MASKED = false>
 __global__ __launch_bounds__(kWavesPerBlock * kWave) void spmm_finish_kernel(GraphView g,
                                                                               const int32_t* __restrict__ long_rows,
@@ -1000,7 +1102,18 @@ int launch_vec(const tagrec_graph* g, const float* X, const EpiArgs& e, hipStrea
     lv.chunk_blocks = static_cast<unsigned>((g->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
   }
   if (e.row_mask) {                       // rows whose mask byte is 0 are left alone (a separate instantiation)
-    spmm_rows_kernel<LPR, EPI, true><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
+    constexpr bool kGroupable = (EPI == EPI_NORMBWD || EPI == EPI_AXPY) && LPR <= 32;
+    bool grouped = false;
+    if constexpr (kGroupable) {
+      // flags always consulted (in_count == NULL) = the hop below the top layer: a handful of flagged operand rows
+      if (e.in_flags && !e.in_count && !e.adam.p) {
+        constexpr int rows_per_block = kWavesPerBlock * (kWave / LPR);
+        const unsigned gblocks = static_cast<unsigned>((g->n_rows + rows_per_block - 1) / rows_per_block);
+        spmm_rows_grouped_kernel<LPR, EPI><<<gblocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
+        grouped = true;
+      }
+    }
+    if (!grouped) spmm_rows_kernel<LPR, EPI, true><<<blocks + lv.chunk_blocks, threads, 0, s>>>(gv, X, e, lv);
     TAGREC_LAUNCH_CHECK();
     if (g->n_long > 0) {
       const unsigned fblocks = static_cast<unsigned>((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock);
