@@ -772,7 +772,8 @@ def _compact(line):
         if r:
             keep[rk] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "mean_launch_ms", "launches_timed",
                                           "frac_of_gather_ceiling", "frac_of_stream_read", "frac_counter", "traffic",
-                                          "step_kernels_ms_per_step", "ms_all_rows_per_layer") if k in r}
+                                          "step_kernels_ms_per_step", "ms_all_rows_per_layer", "shader_clock_mhz_under_kernel",
+                                          "frac_at_measured_clock") if k in r}
     return keep
 
 
