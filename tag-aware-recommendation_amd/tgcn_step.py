@@ -9,14 +9,19 @@ gradients back to table size, the zero-filled full-size gradients of column slic
 Structure of a step (bounded fan-in is what makes it pay: k sampled neighbours per node and relation):
   * `TGCN._needed_rows`: layer l is computed on the rows the batch's loss depends on -- the <= 3 B batch rows at the top, their
     2 k neighbours per row one layer down, ... -- on COMPACT tables (a layer's output holds only those rows, in ascending
-    node order; neighbour ids are renumbered into it through a position map);
+    node order; neighbour ids are renumbered into it through a position map) -- row lists and position maps come from
+    csrc/plan.hip: two launches and one host read per level;
   * forward per layer: Q = X W2 on every input row, P = X[self rows] W1[:D] + b, the six neighbour attentions
     (csrc/tgcn.hip), the fused type-attention / convolution / fusion block (csrc/tgcn_fuse.hip) per node type;
   * the loss reads [ego | normalize(layer 1) | ... | normalize(layer L)] at the batch rows (compact BPR kernels);
   * backward per layer, top down: fused block (input gradients + its weight gradients), attention backward per relation
     (dP, dWT, dv written; dQ and dEj PULLED over the relation's inverted table, the second relation of a neighbour type
     adding the first one's result in the product's epilogue), then dX = dEj + dQ W2^T (+ the self rows' dXs = dT_self +
-    dP W1[:D]^T at their positions) -- every gradient buffer is written once where it is formed.
+    dP W1[:D]^T at their positions) -- every gradient buffer is written once where it is formed;
+  * with `T.Adam(...).fuse_into(model)` the bottom layer's last product dQ W2^T carries the Adam update of the node table
+    in its epilogue (tagrec_tall_mm_adam_f32): the tables' gradients are never stored, the optimizer gets None for them.
+No host read after the plan: the inverted tables are created without one (`Graph(..., deferred=True)`), so the host has
+the whole step queued a few ms in (tools/c4_host_timeline.py).
 
 Same loss and gradients as the all-rows pass (`TGCN.forward()` + triplet loss + autograd): tests/test_gpu_tgcn.py.
 """
