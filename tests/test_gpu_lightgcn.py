@@ -146,6 +146,44 @@ def test_workspace_backed_graph_handles():
     assert float(empty.spmm(torch.ones(7, 8, device=DEV)).abs().sum()) == 0.0
 
 
+def test_deferred_graph_handles_need_no_host_read_and_give_the_same_products():
+    """`Graph(..., workspace=True, deferred=True)`: the handle of a matrix built inside a training step without the host read
+    of the long-row counters (the TGCN step's inverted tables) -- the work list is sized by its upper bounds and its unused
+    slots are skipped.  Bit-identical products with the ordinary handle, long rows, every vector width, `like()` twins and the
+    masked / flagged hops included."""
+    rng = np.random.RandomState(3)
+    csr = _star_graph(6000, 5000, rng)
+    ref = _graph(csr)
+    g = T.Graph(ref.rowptr, ref.col, ref.val, ref.shape, workspace=True, deferred=True)
+    assert g.info()["n_long_rows"] >= 2                               # an upper bound, not a count
+    gen = torch.Generator().manual_seed(5)
+    for D in (8, 64, 256):
+        X = torch.randn(ref.shape[1], D, generator=gen).to(DEV)
+        assert torch.equal(g.spmm(X), ref.spmm(X))
+    col2 = torch.randint(0, 333, (ref.nnz,), generator=gen, dtype=torch.int32).to(DEV)
+    val2 = torch.randn(ref.nnz, generator=gen).to(DEV)
+    twin, fresh = g.like(col2, val2, 333), T.Graph(ref.rowptr, col2, val2, (6000, 333))
+    X = torch.randn(333, 32, generator=gen).to(DEV)
+    assert torch.equal(twin.spmm(X), fresh.spmm(X))
+    # a masked hop with a few flagged operand rows (the row-per-lane-group kernel + the chunked long rows)
+    n_r, n_c = ref.shape
+    X = torch.randn(n_c, 64, generator=gen).to(DEV)
+    flags = torch.zeros(n_c, dtype=torch.uint8, device=DEV)
+    flags[torch.randint(0, n_c, (40,), generator=gen).to(DEV)] = 1
+    X = X * flags[:, None]
+    mask = (torch.rand(n_r, generator=gen) < 0.5).to(torch.uint8).to(DEV)
+    B = torch.randn(n_r, 64, generator=gen).to(DEV)
+    outs = []
+    for h in (g, ref):
+        o = torch.zeros(n_r, 64, device=DEV)
+        h.spmm_axpy_sparse(X, flags, None, B, 0.5, o, row_mask=mask)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    want = (torch.sparse_csr_tensor(ref.rowptr, ref.col.long(), ref.val.double(), size=ref.shape) @ X.double() + 0.5 * B.double()).float()
+    np.testing.assert_allclose((outs[0] * mask[:, None]).cpu().numpy(), (want * mask[:, None]).cpu().numpy(), rtol=2e-5, atol=2e-5)
+    assert float((outs[0] * (1 - mask)[:, None].float()).abs().sum()) == 0.0          # rows outside the mask are not touched
+
+
 def test_spmm_rejects_bad_arguments():
     rng = np.random.RandomState(1)
     csr = oadj.coo_to_csr(rng.randint(0, 100, 500), rng.randint(0, 100, 500), rng.rand(500), (100, 100))
