@@ -790,7 +790,7 @@ __global__ __launch_bounds__(kFuseThreads) void tgcn_fuse_bwd_kernel(
 //   A  type attention (full vectors, transient) -> bw; vector-level pre-activations -> dpv, yvec, dfeat
 //   B  for half h: e_h = bw t_h; main (c, b) loop over the b-blocks of the half (same LDS ring of Wf rows, the stream now
 //      runs half 0 of every filter, then half 1); vector-level contribution; partial softmax dots; de_h -> dT (scratch)
-//   C  type attention again (192 MFMAs against the main loop's 8192) for the pre-activations -> dS, dq, dp
+//   C  the type attention's pre-activations (kept in LDS since A) -> dS, dq, dp
 //   D  dt = bw de + U dS, reading de back from dT
 template <int D, int DOUT, int A>
 __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
@@ -809,6 +809,10 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
   constexpr int NBUF = 3, CPH = HB / NB, NCH = 2 * kBitC * CPH;   // chunks per (filter, half); chunks per tile group
   static_assert(HB % NB == 0 && CPH >= 1 && NCH >= 4, "tgcn_fuse_bwd2: unsupported shape");
   __shared__ __attribute__((aligned(1024))) char wbuf[NBUF][CHUNK];
+  // the type attention's pre-activations of the tile (3 A / 4 floats per lane), kept from phase A for phase C: recomputing
+  // them there (192 MFMAs fed by 96 row loads and the U stream) cost 3.5 % of the kernel, the registers to hold them
+  // through phase B do not exist
+  __shared__ f32x4 sc_keep[3 * AB][kFuseThreads];
   for (int i = threadIdx.x; i < NSM; i += kFuseThreads) sh[i] = 0.f;
   for (int i = threadIdx.x; i < 3 * kBitC * 4; i += kFuseThreads) sh_wb4[i] = 0.f;
   __syncthreads();
@@ -876,6 +880,10 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
       for (int j = 0; j < 3; ++j) load_seg<DS>(Tj[j] + node * D + q * DS, ok, e3[j]);
       f32x4 sc[3][AB];
       type_attention<D, A>(e3, U, qv, pv, r, q, sc, bw);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int ab = 0; ab < AB; ++ab) sc_keep[j * AB + ab][threadIdx.x] = sc[j][ab];      // (read back by this thread only)
       f32x4 pre[6];
       vector_conv<D>(e3, w1, w2, w3, r, q, pre);
 #pragma unroll
@@ -1013,15 +1021,14 @@ __global__ __launch_bounds__(kFuseThreads, 2) void tgcn_fuse_bwd2_kernel(
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) db[j] = quad_sum(db[j]);
-    // ---- C: through the type-level softmax (pre-activations recomputed)
+    // ---- C: through the type-level softmax (pre-activations kept in LDS since phase A)
     float dsv[3][AS];
     {
-      float t[3][DS];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) load_seg<DS>(Tj[j] + node * D + q * DS, ok, t[j]);
       f32x4 sc[3][AB];
-      float bw2[3];
-      type_attention<D, A>(t, U, qv, pv, r, q, sc, bw2);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int ab = 0; ab < AB; ++ab) sc[j][ab] = sc_keep[j * AB + ab][threadIdx.x];
       const float mix = bw[0] * db[0] + bw[1] * db[1] + bw[2] * db[2];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
