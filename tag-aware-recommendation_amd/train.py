@@ -41,6 +41,9 @@ class Adam:
     def fuse_into(self, model):
         """Let `model` apply this optimizer's update of its embedding table inside the last kernel of its backward pass
         (the gradient row is consumed where it is formed: no gradient tensor, no separate Adam launch over the table).
+        LightGCN / NGCF: `model.table`, in the epilogue of the last backward product; TGCN: the three node tables
+        (`model.fused_tables()`), in the epilogue of the bottom layer's dQ W_2^T product of the BPR phase -- the TransTag
+        phase and every other path hand out gradients as usual.
         The zero_grad() / backward() / step() protocol of basic_train.py:19-25 is unchanged: step() then only counts
         the step for that parameter.  One backward() per step().  With capturable=True (models that declare
         `fused_capturable`: LightGCN, NGCF) the step counter and the step-dependent factors live in device memory and
