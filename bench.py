@@ -605,10 +605,15 @@ def run_table_model(args, dev, rank, world, sharded, ceilings=None, ds=None, lig
     if args.model == "lightgcn" and not sharded and not light and getattr(model, "restrict_forward", False):
         # the same step with every forward layer computed on ALL rows (the timed step above computes the top two
         # layers only on the rows the batch's loss depends on -- same loss and gradients)
+        ws_mb = round(model.step_ws.nbytes() / 2 ** 20, 1) if getattr(model, "step_ws", None) is not None else None
+        if ws_mb is not None:
+            model.step_ws.clear()          # the all-rows step does not use the workspace and needs its memory at the C5 shape
+            torch.cuda.empty_cache()
         model.restrict_forward = False
         run_steps(batches[:W])
         dtf, _ = timed(batches[W:])
         model.restrict_forward = True
+        extra["step_workspace_MB"] = ws_mb
         extra["ms_per_step_all_rows_forward"] = dtf / K * 1e3
         extra["triplets_per_s_all_rows_forward"] = K * B / dtf
     if args.big_batch and epoch.shape[0] >= args.big_batch * 3 and not sharded and not light:

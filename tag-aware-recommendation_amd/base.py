@@ -49,6 +49,15 @@ class StepWorkspace:
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self._buf.values())
 
+    def clear(self):
+        """Give the buffers back to the allocator (they are re-created by the next restricted step): before a phase that
+        needs the memory for something else -- an all-rows pass at the C5 shape holds six more [N, D] tensors.  Refused
+        while a forward pass still owns them."""
+        if self._owner is not None and self._owner() is not None:
+            return False
+        self._buf = {}
+        return True
+
 
 class _Token:
     pass
