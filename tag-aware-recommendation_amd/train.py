@@ -133,6 +133,11 @@ class Adam:
         # which the GPU caught up with the host at the end of every step
         for t, group in small.items():
             k = len(group)
+            if k < 3:                                     # a model with one or two tensors: the plain launch is cheaper to set up
+                for pd, g_, m_, v_ in group:
+                    _lib.check(lib.tagrec_adam_f32(_lib.ptr(pd), _lib.ptr(g_), _lib.ptr(m_), _lib.ptr(v_), pd.numel(), self.lr,
+                                                   self.betas[0], self.betas[1], self.eps, t, _lib.stream_ptr()), "adam")
+                continue
             arr = [(_lib.ctypes.c_void_p * k)(*[x[i].data_ptr() for x in group]) for i in range(4)]
             n = (_lib.ctypes.c_int64 * k)(*[x[0].numel() for x in group])
             _lib.check(lib.tagrec_adam_multi_f32(k, arr[0], arr[1], arr[2], arr[3], n, self.lr, self.betas[0], self.betas[1], self.eps,
