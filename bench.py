@@ -25,8 +25,14 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fused
 (`spmm_rows_kernel<16, NORM_ACC>`, run without the layer-mean accumulator: the training step forms the mean on the
 batch rows): algorithmic bytes per launch ((8+4D) per stored entry + (8+4D) per row + 4 per row for the
 norm) divided by its mean duration from HIP events recorded on the launch stream inside the timed region.
+`roofline.measured_ceilings` are probe kernels of the library run before the timed region (stream triad / copy / read,
+random 256-byte-row gathers from 256 MB / 512 MB / 4 GB tables), `frac_of_gather_ceiling` prices the kernel against them.
 `cpu_baseline` times the CPU oracle (PyTorch CPU restatement of the reference path, checked against
-the reference in tests/golden) on the same graph and batch size, on the box's host cores.
+the reference in tests/golden) on the same graph and batch size, on the box's host cores: 1 warm-up + 3 timed steps.
+At N = 1 the headline run also carries `extra.configs.C3` (NGCF, same graph) and `.C4` (TGCN, 1 M / 1 M / 2 M nodes; with
+the shader clock measured under its fused kernel) as short legs in the same process, and `extra.hip_graph_replay` (the same
+C2 step as one captured HIP graph).  `--model ngcf|tgcn|dgcf|...` run those models on their own.
+NOTE: the multi-rank path has been verified over gloo and in an RCCL group of one; it has never run over xGMI.
 """
 import argparse
 import json
