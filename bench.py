@@ -854,7 +854,7 @@ def main():
             del ds
             torch.cuda.empty_cache()
             print("[bench] extra.configs: C4 TGCN leg ...", file=sys.stderr, flush=True)
-            legs["C4"] = _compact(bench_tgcn(_leg_args(args, model="tgcn", steps=3, warmup=1, dim=128), ceilings))
+            legs["C4"] = _compact(bench_tgcn(_leg_args(args, model="tgcn", steps=8, warmup=3, dim=128), ceilings))
             out["extra"]["configs"] = legs
         ds = None
         torch.cuda.empty_cache()
